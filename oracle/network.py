@@ -1,0 +1,275 @@
+"""ORACLE (test infrastructure) -- DQNNet forward + iS-DQN loss/grad/Adam/shift, CPU.
+
+PARITY UNPINNED for the floating-point network numerics: the arithmetic of the
+reference lives in flax==0.10.2 (``nn.Conv``, ``nn.LayerNorm``, ``nn.Dense``),
+jax==0.4.30 (``jax.grad``) and optax==0.2.4 (``adam``) -- pinned in the
+reference's setup.cfg:14-32, absent from this image -- and the reference's
+tests/test_isdqn.py holds formulas, not numbers.  This file restates the
+documented behaviour of those versions at the reference's own call sites:
+
+  * ``DQNNet.__call__`` cnn / fc branches ... slimdqn/networks/architectures/dqn.py:47-74, 89-103
+      - ``x / 255.0``; ``nn.Conv`` default padding "SAME" (asymmetric: lo = total//2),
+        use_bias, kernel HWIO, activations NHWC;
+      - ``nn.LayerNorm`` defaults: normalise + scale/bias over the LAST axis only,
+        epsilon 1e-6, fast variance  var = max(0, E[x^2] - E[x]^2),
+        y = (x - mean) * (rsqrt(var + eps) * scale) + bias;
+      - flatten order (h, w, c); ``nn.Dense`` kernel (in, out);
+      - module auto-names Conv_i / LayerNorm_i / Dense_i counted per class.
+  * initialisers .............................. dqn.py:49, 90: xavier_uniform
+        (limit sqrt(6/(fan_in+fan_out)), conv fans x receptive field) for cnn,
+        lecun_normal (truncated normal, std sqrt(1/fan_in)/0.87962566103423978) for fc;
+        biases 0, LayerNorm scale 1 / bias 0.  (JAX threefry streams are not
+        reproducible offline: draws come from numpy PCG64 instead.)
+  * iSDQN.loss_on_batch / compute_target ....... slimdqn/networks/isdqn.py:92-109
+  * iSDQN.learn_on_batch (grad + optax.adam) ... isdqn.py:82-90, 46
+        adam: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; t += 1 ;
+        p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)       (eps_root = 0)
+  * iSDQN.shift_params ......................... isdqn.py:111-125 (moments untouched)
+  * iSDQN.best_action .......................... isdqn.py:127-135
+
+Gradients come from torch autograd on the restated forward (an implementation
+independent of the hand-derived HIP backward); ``forward_numpy`` is a second,
+plain-numpy im2col statement of the forward used to cross-check the torch one.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-6
+ADAM_B1, ADAM_B2 = 0.9, 0.999
+
+# (kernel, stride) of the three cnn torso convolutions (dqn.py:55, 62, 69)
+CNN_GEOMETRY = ((8, 4), (4, 2), (3, 1))
+
+
+def same_padding(size: int, kernel: int, stride: int):
+    """JAX/Flax "SAME": out = ceil(in/stride); lo = total//2; hi = total-lo."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + kernel - size, 0)
+    lo = total // 2
+    return out, lo, total - lo
+
+
+def layer_names(features: Sequence[int], architecture_type: str, layer_norm: bool):
+    """Ordered (module_name, kind) list as Flax auto-names them."""
+    names = []
+    n_conv = n_ln = n_dense = 0
+    if architecture_type == "cnn":
+        for _ in range(3):
+            names.append((f"Conv_{n_conv}", "conv"))
+            n_conv += 1
+            if layer_norm:
+                names.append((f"LayerNorm_{n_ln}", "ln"))
+                n_ln += 1
+        start = 3
+    elif architecture_type == "fc":
+        start = 0
+    else:
+        raise ValueError(architecture_type)
+    for _ in range(start, len(features)):
+        names.append((f"Dense_{n_dense}", "dense"))
+        n_dense += 1
+        if layer_norm:
+            names.append((f"LayerNorm_{n_ln}", "ln"))
+            n_ln += 1
+    names.append((f"Dense_{n_dense}", "dense"))
+    return names
+
+
+def init_params(
+    seed: int,
+    observation_dim: Sequence[int],
+    features: Sequence[int],
+    architecture_type: str,
+    final_feature: int,
+    layer_norm: bool,
+) -> Dict[str, Dict[str, np.ndarray]]:
+    """Flax-layout parameter pytree (the inner ``params["params"]`` dict), float32."""
+    rng = np.random.default_rng(seed)
+    params: Dict[str, Dict[str, np.ndarray]] = {}
+
+    def xavier(shape, fan_in, fan_out):
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+    def lecun(shape, fan_in):
+        std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+        out = np.empty(int(np.prod(shape)), dtype=np.float64)
+        filled = 0
+        while filled < out.size:  # truncated normal on [-2, 2]
+            draw = rng.standard_normal(out.size - filled)
+            draw = draw[np.abs(draw) <= 2.0]
+            out[filled : filled + draw.size] = draw
+            filled += draw.size
+        return (out.reshape(shape) * std).astype(np.float32)
+
+    n_conv = n_ln = n_dense = 0
+
+    def add_ln(width):
+        nonlocal n_ln
+        if layer_norm:
+            params[f"LayerNorm_{n_ln}"] = {
+                "scale": np.ones(width, np.float32),
+                "bias": np.zeros(width, np.float32),
+            }
+            n_ln += 1
+
+    if architecture_type == "cnn":
+        h, w, c = observation_dim
+        for i, (k, s) in enumerate(CNN_GEOMETRY):
+            cout = int(features[i])
+            params[f"Conv_{n_conv}"] = {
+                "kernel": xavier((k, k, c, cout), k * k * c, k * k * cout),
+                "bias": np.zeros(cout, np.float32),
+            }
+            n_conv += 1
+            add_ln(cout)
+            h = same_padding(h, k, s)[0]
+            w = same_padding(w, k, s)[0]
+            c = cout
+        width = h * w * c
+        dense_feats = [int(f) for f in features[3:]]
+        init = lambda shape: xavier(shape, shape[0], shape[1])
+    elif architecture_type == "fc":
+        width = int(np.prod(observation_dim))
+        dense_feats = [int(f) for f in features]
+        init = lambda shape: lecun(shape, shape[0])
+    else:
+        raise ValueError(architecture_type)
+
+    for f in dense_feats:
+        params[f"Dense_{n_dense}"] = {"kernel": init((width, f)), "bias": np.zeros(f, np.float32)}
+        n_dense += 1
+        add_ln(f)
+        width = f
+    params[f"Dense_{n_dense}"] = {
+        "kernel": init((width, final_feature)),
+        "bias": np.zeros(final_feature, np.float32),
+    }
+    return params
+
+
+# ----------------------------------------------------------------------------- torch forward
+def _layer_norm(x: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    mean = x.mean(dim=-1, keepdim=True)
+    mean2 = (x * x).mean(dim=-1, keepdim=True)
+    var = torch.clamp(mean2 - mean * mean, min=0.0)
+    mul = torch.rsqrt(var + LN_EPS) * scale
+    return (x - mean) * mul + bias
+
+
+def _conv_same(x_nhwc: torch.Tensor, kernel_hwio: torch.Tensor, bias: torch.Tensor, stride: int) -> torch.Tensor:
+    kh, kw = kernel_hwio.shape[0], kernel_hwio.shape[1]
+    _, plo_h, phi_h = same_padding(x_nhwc.shape[1], kh, stride)
+    _, plo_w, phi_w = same_padding(x_nhwc.shape[2], kw, stride)
+    x = x_nhwc.permute(0, 3, 1, 2)
+    x = F.pad(x, (plo_w, phi_w, plo_h, phi_h))
+    y = F.conv2d(x, kernel_hwio.permute(3, 2, 0, 1), bias=bias, stride=stride)
+    return y.permute(0, 2, 3, 1)
+
+
+def forward(params, x, features, architecture_type: str, layer_norm: bool, capture: dict | None = None):
+    """DQNNet.__call__ (dqn.py:47-103) for a batch.  ``params``: dict of dicts of torch tensors.
+
+    x: (N,84,84,4) raw pixel values (any dtype; converted, then /255) for cnn, (N,obs) for fc.
+    Returns (N, final_feature).  ``capture`` (optional dict) receives the post-activation of
+    every hidden layer under the module name that produced it.
+    """
+    dtype = next(iter(next(iter(params.values())).values())).dtype
+    n_ln = n_dense = 0
+    x = x.to(dtype)
+    if architecture_type == "cnn":
+        x = x / 255.0
+        for i, (_k, s) in enumerate(CNN_GEOMETRY):
+            p = params[f"Conv_{i}"]
+            x = _conv_same(x, p["kernel"], p["bias"], s)
+            if layer_norm:
+                q = params[f"LayerNorm_{n_ln}"]
+                x = _layer_norm(x, q["scale"], q["bias"])
+                n_ln += 1
+            x = torch.relu(x)
+            if capture is not None:
+                capture[f"Conv_{i}"] = x
+        x = x.reshape(x.shape[0], -1)
+        start = 3
+    else:
+        x = x.reshape(x.shape[0], -1)
+        start = 0
+    for _ in range(start, len(features)):
+        p = params[f"Dense_{n_dense}"]
+        x = x @ p["kernel"] + p["bias"]
+        if layer_norm:
+            q = params[f"LayerNorm_{n_ln}"]
+            x = _layer_norm(x, q["scale"], q["bias"])
+            n_ln += 1
+        x = torch.relu(x)
+        if capture is not None:
+            capture[f"Dense_{n_dense}"] = x
+        n_dense += 1
+    p = params[f"Dense_{n_dense}"]
+    return x @ p["kernel"] + p["bias"]
+
+
+def to_torch(params_np, dtype=torch.float32, requires_grad=False):
+    out = {}
+    for mod, leaves in params_np.items():
+        out[mod] = {}
+        for name, arr in leaves.items():
+            t = torch.tensor(np.asarray(arr), dtype=dtype)
+            t.requires_grad_(requires_grad)
+            out[mod][name] = t
+    return out
+
+
+def to_numpy(params_t):
+    return {m: {n: t.detach().cpu().numpy().copy() for n, t in leaves.items()} for m, leaves in params_t.items()}
+
+
+# ----------------------------------------------------------------------------- numpy cross-check
+def forward_numpy(params_np, x, features, architecture_type: str, layer_norm: bool):
+    """Plain-numpy float64 statement of the same forward (im2col loops; small inputs only)."""
+    x = np.asarray(x, np.float64)
+    P = {m: {n: np.asarray(a, np.float64) for n, a in l.items()} for m, l in params_np.items()}
+
+    def ln(z, q):
+        mean = z.mean(-1, keepdims=True)
+        var = np.maximum((z * z).mean(-1, keepdims=True) - mean * mean, 0.0)
+        return (z - mean) * (1.0 / np.sqrt(var + LN_EPS) * q["scale"]) + q["bias"]
+
+    n_ln = n_dense = 0
+    if architecture_type == "cnn":
+        x = x / 255.0
+        for i, (k, s) in enumerate(CNN_GEOMETRY):
+            W, b = P[f"Conv_{i}"]["kernel"], P[f"Conv_{i}"]["bias"]
+            N, H, Wd, C = x.shape
+            oh, plo_h, phi_h = same_padding(H, k, s)
+            ow, plo_w, phi_w = same_padding(Wd, k, s)
+            xp = np.zeros((N, H + plo_h + phi_h, Wd + plo_w + phi_w, C))
+            xp[:, plo_h : plo_h + H, plo_w : plo_w + Wd] = x
+            y = np.zeros((N, oh, ow, W.shape[3]))
+            for oy in range(oh):
+                for ox in range(ow):
+                    patch = xp[:, oy * s : oy * s + k, ox * s : ox * s + k, :]
+                    y[:, oy, ox, :] = np.tensordot(patch, W, axes=([1, 2, 3], [0, 1, 2])) + b
+            if layer_norm:
+                y = ln(y, P[f"LayerNorm_{n_ln}"])
+                n_ln += 1
+            x = np.maximum(y, 0.0)
+        x = x.reshape(x.shape[0], -1)
+        start = 3
+    else:
+        x = x.reshape(x.shape[0], -1)
+        start = 0
+    for _ in range(start, len(features)):
+        x = x @ P[f"Dense_{n_dense}"]["kernel"] + P[f"Dense_{n_dense}"]["bias"]
+        if layer_norm:
+            x = ln(x, P[f"LayerNorm_{n_ln}"])
+            n_ln += 1
+        x = np.maximum(x, 0.0)
+        n_dense += 1
+    return x @ P[f"Dense_{n_dense}"]["kernel"] + P[f"Dense_{n_dense}"]["bias"]
