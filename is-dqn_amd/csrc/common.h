@@ -1,0 +1,60 @@
+// Shared helpers for the gfx950 iS-DQN kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/isdqn_hip.h"
+
+namespace isdqn {
+
+void set_last_error(const char* fmt, ...);
+
+#define ISDQN_HIP_CHECK(expr)                                                                         \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            ::isdqn::set_last_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                                    __LINE__);                                                        \
+            return ISDQN_ERR_HIP;                                                                     \
+        }                                                                                             \
+    } while (0)
+
+#define ISDQN_REQUIRE(cond, code, msg)                                         \
+    do {                                                                       \
+        if (!(cond)) {                                                         \
+            ::isdqn::set_last_error("%s (%s:%d)", msg, __FILE__, __LINE__);    \
+            return code;                                                       \
+        }                                                                      \
+    } while (0)
+
+// Unsigned division by a runtime constant, valid for 0 <= n < 2^31 (all index spaces here are < 2^31).
+struct FastDiv {
+    uint32_t d, m, sh;
+    __host__ __device__ FastDiv() : d(1), m(0), sh(0) {}
+    __host__ __device__ explicit FastDiv(uint32_t div) : d(div), m(0), sh(0) {
+        if (div > 1) {
+            uint32_t lg = 0;
+            while ((1u << lg) < div) ++lg;  // ceil(log2(div))
+            uint32_t p = 31 + lg;
+            m = (uint32_t)(((1ull << p) + div - 1) / div);
+            sh = p - 32;
+        }
+    }
+    __host__ __device__ __forceinline__ uint32_t div(uint32_t n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return d == 1 ? n : (__umulhi(n, m) >> sh);
+#else
+        return d == 1 ? n : (uint32_t)((((uint64_t)n * m) >> 32) >> sh);
+#endif
+    }
+    __host__ __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const {
+        q = div(n);
+        r = n - q * d;
+    }
+};
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+}  // namespace isdqn

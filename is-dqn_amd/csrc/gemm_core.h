@@ -1,0 +1,306 @@
+// MFMA tile engine for gfx950 (CDNA4): one templated kernel, pluggable operand loaders and
+// epilogues.  Every dense contraction of the iS-DQN step (implicit-GEMM convolutions,
+// dense layers, their data- and weight-gradients) is an instance of
+//
+//      C[m][n] = sum_k A(m, k) * B(n, k)
+//
+// with fp32 data in HBM, bf16 MFMA (v_mfma_f32_16x16x32_bf16) and fp32 accumulation.
+//
+// Operand staging: global -> registers (8-element chunks fetched by a problem-specific
+// loader functor: im2col gathers, uint8 frame decode, ...) -> bf16 split -> LDS, double
+// buffered, one barrier per 32-deep K step.  An operand is staged in one of two images:
+//   ROW : LDS tile [rows][32 k]  (k contiguous)  -> fragments by ds_read_b128
+//   TR  : LDS tile [32 k][rows]  (rows contiguous: the contraction index is the slow
+//         one in memory, as in every weight-gradient) -> fragments by the gfx950
+//         transposing read ds_read_b64_tr_b16, so no operand is ever transposed in HBM.
+//
+// Precision (PASSES): 1 = plain bf16; 3 = split-bf16 (x = hi + lo, both bf16):
+//   hi*hi + lo*hi + hi*lo  -> ~2^-17 relative, fp32-class results at 3/16 of the fp32
+//   MFMA cost instead of 16/16;  2 = same with an operand B that is exact in bf16
+//   (uint8 pixels), so its lo plane is skipped.
+#pragma once
+#include "common.h"
+
+namespace isdqn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int GEMM_BK = 32;
+constexpr int GEMM_THREADS = 256;
+
+#define LDS_AS __attribute__((address_space(3)))
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __bf16 h = (__bf16)v[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(v[i] - (float)h);
+    }
+}
+__device__ __forceinline__ void round8(const float (&v)[8], bf16x8& hi) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hi[i] = (__bf16)v[i];
+}
+
+// LDS image geometry (in bf16 elements)
+template <int ROWS, bool TR>
+struct TileGeom {
+    static constexpr int PITCH = TR ? (ROWS + 8) : (GEMM_BK + 8);
+    static constexpr int ELEMS = TR ? GEMM_BK * PITCH : ROWS * PITCH;
+    static constexpr int CHUNKS = ROWS * (GEMM_BK / 8);  // 8-element chunks per K step (same for both images)
+    static constexpr int PER_THREAD = (CHUNKS + GEMM_THREADS - 1) / GEMM_THREADS;
+};
+
+// Fragment of 16 rows x 32 k for lane `lane`: element j <-> (row = row0 + (lane&15), k = 8*(lane>>4) + j).
+template <bool TR, int PITCH>
+__device__ __forceinline__ bf16x8 read_frag(const __bf16* tile, int row0, int lane) {
+    if constexpr (!TR) {
+        return *reinterpret_cast<const bf16x8*>(tile + (row0 + (lane & 15)) * PITCH + (lane >> 4) * 8);
+    } else {
+        // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(rows) block; lane 4q+p supplies the address of
+        // k-row q, rows 4p..4p+3; lane i receives row i of the 4 k-rows.
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        const __bf16* a0 = tile + (8 * g + q) * PITCH + row0 + 4 * p;
+        const __bf16* a1 = a0 + 4 * PITCH;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)a0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)a1);
+        s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, r);
+    }
+}
+
+// A "problem" P supplies:
+//   static constexpr int BM, BN, WM, WN;   block tile and wave grid (WM*WN == 4)
+//   static constexpr bool A_TR, B_TR;      LDS image per operand
+//   static constexpr int PASSES;           1, 2 or 3
+//   struct Tile { int m0, n0, k0, k1; ... }            k range in elements, k0 % 32 == 0
+//   __device__ bool tile(int block, Tile&) const
+//   ACtx / BCtx + a_ctx(tile, fixed) / b_ctx(tile, fixed)
+//        ROW image: fixed = absolute row (m0 + r),      varying = absolute k of the chunk (8 along k)
+//        TR  image: fixed = absolute first row of the chunk (8 along rows), varying = absolute k
+//   __device__ void load_a(const Tile&, const ACtx&, int varying, float (&v)[8]) const   (same for b)
+//   __device__ void epilogue(const Tile&, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const
+//        acc[mt][nt][r] <-> C[m_wave + mt*16 + (lane>>4)*4 + r][n_wave + nt*16 + (lane&15)]
+template <class P>
+struct GemmTraits {
+    static constexpr int BM = P::BM, BN = P::BN, WM = P::WM, WN = P::WN;
+    static constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
+    static constexpr int PASSES = P::PASSES;
+    static constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
+    static constexpr int B_PLANES = PASSES >= 3 ? 2 : 1;
+    using GA = TileGeom<BM, P::A_TR>;
+    using GB = TileGeom<BN, P::B_TR>;
+    static constexpr int STAGE_ELEMS = A_PLANES * GA::ELEMS + B_PLANES * GB::ELEMS;
+    static constexpr int LDS_BYTES = 2 * STAGE_ELEMS * 2;
+};
+
+template <class P>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
+    using T = GemmTraits<P>;
+    using GA = typename T::GA;
+    using GB = typename T::GB;
+    constexpr int MT = T::MT, NT = T::NT, PASSES = T::PASSES;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+
+    typename P::Tile tile;
+    if (!p.tile((int)blockIdx.x, tile)) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / P::WN, wn = wave % P::WN;
+    const int wave_m = wm * (MT * 16), wave_n = wn * (NT * 16);
+
+    // ---- per-thread staging assignments (k-invariant part) ----
+    typename P::ACtx actx[GA::PER_THREAD];
+    typename P::BCtx bctx[GB::PER_THREAD];
+    int a_lds[GA::PER_THREAD], a_var[GA::PER_THREAD];
+    int b_lds[GB::PER_THREAD], b_var[GB::PER_THREAD];
+    bool a_on[GA::PER_THREAD], b_on[GB::PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < GA::PER_THREAD; ++i) {
+        int c = tid + i * GEMM_THREADS;
+        a_on[i] = c < GA::CHUNKS;
+        if (!a_on[i]) c = 0;
+        if constexpr (!P::A_TR) {
+            int r = c >> 2, kc = c & 3;
+            actx[i] = p.a_ctx(tile, tile.m0 + r);
+            a_var[i] = kc * 8;
+            a_lds[i] = r * GA::PITCH + kc * 8;
+        } else {
+            int kk = c / (T::BM / 8), rc = c % (T::BM / 8);
+            actx[i] = p.a_ctx(tile, tile.m0 + rc * 8);
+            a_var[i] = kk;
+            a_lds[i] = kk * GA::PITCH + rc * 8;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GB::PER_THREAD; ++i) {
+        int c = tid + i * GEMM_THREADS;
+        b_on[i] = c < GB::CHUNKS;
+        if (!b_on[i]) c = 0;
+        if constexpr (!P::B_TR) {
+            int r = c >> 2, kc = c & 3;
+            bctx[i] = p.b_ctx(tile, tile.n0 + r);
+            b_var[i] = kc * 8;
+            b_lds[i] = r * GB::PITCH + kc * 8;
+        } else {
+            int kk = c / (T::BN / 8), rc = c % (T::BN / 8);
+            bctx[i] = p.b_ctx(tile, tile.n0 + rc * 8);
+            b_var[i] = kk;
+            b_lds[i] = kk * GB::PITCH + rc * 8;
+        }
+    }
+
+    float sa[GA::PER_THREAD][8], sb[GB::PER_THREAD][8];
+
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < GA::PER_THREAD; ++i)
+            if (a_on[i]) p.load_a(tile, actx[i], k + a_var[i], sa[i]);
+#pragma unroll
+        for (int i = 0; i < GB::PER_THREAD; ++i)
+            if (b_on[i]) p.load_b(tile, bctx[i], k + b_var[i], sb[i]);
+    };
+    auto stash = [&](int stage) {
+        __bf16* base = smem + stage * T::STAGE_ELEMS;
+        __bf16* a_hi = base;
+        __bf16* a_lo = base + GA::ELEMS;
+        __bf16* b_hi = base + T::A_PLANES * GA::ELEMS;
+        __bf16* b_lo = b_hi + GB::ELEMS;
+#pragma unroll
+        for (int i = 0; i < GA::PER_THREAD; ++i) {
+            if (!a_on[i]) continue;
+            bf16x8 hi, lo;
+            if constexpr (PASSES >= 2) {
+                split8(sa[i], hi, lo);
+                *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
+            } else {
+                round8(sa[i], hi);
+            }
+            *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
+        }
+#pragma unroll
+        for (int i = 0; i < GB::PER_THREAD; ++i) {
+            if (!b_on[i]) continue;
+            bf16x8 hi, lo;
+            if constexpr (PASSES >= 3) {
+                split8(sb[i], hi, lo);
+                *reinterpret_cast<bf16x8*>(b_lo + b_lds[i]) = lo;
+            } else {
+                round8(sb[i], hi);
+            }
+            *reinterpret_cast<bf16x8*>(b_hi + b_lds[i]) = hi;
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int stage) {
+        const __bf16* base = smem + stage * T::STAGE_ELEMS;
+        const __bf16* a_hi = base;
+        const __bf16* a_lo = base + GA::ELEMS;
+        const __bf16* b_hi = base + T::A_PLANES * GA::ELEMS;
+        const __bf16* b_lo = b_hi + GB::ELEMS;
+        bf16x8 fa_hi[MT], fa_lo[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            fa_hi[mt] = read_frag<P::A_TR, GA::PITCH>(a_hi, wave_m + mt * 16, lane);
+            if constexpr (PASSES >= 2) fa_lo[mt] = read_frag<P::A_TR, GA::PITCH>(a_lo, wave_m + mt * 16, lane);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bf16x8 fb_hi = read_frag<P::B_TR, GB::PITCH>(b_hi, wave_n + nt * 16, lane);
+            bf16x8 fb_lo;
+            if constexpr (PASSES >= 3) fb_lo = read_frag<P::B_TR, GB::PITCH>(b_lo, wave_n + nt * 16, lane);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (PASSES >= 3)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_lo, acc[mt][nt], 0, 0, 0);
+                if constexpr (PASSES >= 2)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[mt], fb_hi, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_hi, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop: one barrier per K step, loads of step s+1 in flight under the MFMAs of step s ----
+    const int nsteps = (tile.k1 - tile.k0 + GEMM_BK - 1) / GEMM_BK;
+    if (nsteps > 0) {
+        fetch(tile.k0);
+        stash(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const bool more = s + 1 < nsteps;
+            if (more) fetch(tile.k0 + (s + 1) * GEMM_BK);
+            compute(s & 1);
+            if (more) stash((s + 1) & 1);
+            __syncthreads();
+        }
+    }
+    p.epilogue(tile, acc, tile.m0 + wave_m, tile.n0 + wave_n, lane);
+}
+
+template <class P>
+static int launch_gemm(const P& p, int n_blocks, hipStream_t stream) {
+    using T = GemmTraits<P>;
+    static bool configured = false;
+    if (!configured) {
+        if (T::LDS_BYTES > 65536)
+            ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<P>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        configured = true;
+    }
+    if (n_blocks <= 0) return ISDQN_OK;
+    hipLaunchKernelGGL(gemm_kernel<P>, dim3(n_blocks), dim3(GEMM_THREADS), T::LDS_BYTES, stream, p);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// Generic operand loaders over row-major fp32 matrices
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void zero8(float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+}
+__device__ __forceinline__ void load8_aligned(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// Matrix X[rows][ld] (row-major).  `inner` bounds the contiguous index, `outer` the strided one.
+// ROW image: fixed = row (outer), varying = first k of the chunk (inner).
+// TR  image: fixed = first row of the chunk (inner!), varying = k (outer).
+// `aligned8` promises base 16-B aligned, ld % 4 == 0 and inner % 8 == 0 (chunks never straddle the bound).
+struct MatSrc {
+    const float* base;
+    int ld, outer, inner;
+    int aligned8;
+    __device__ __forceinline__ void load(int o, int i0, float (&v)[8]) const {
+        if (o >= outer || i0 >= inner) {
+            zero8(v);
+            return;
+        }
+        const float* p = base + (int64_t)o * ld + i0;
+        if (aligned8) {
+            load8_aligned(p, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (i0 + j < inner) ? p[j] : 0.f;
+        }
+    }
+};
+
+}  // namespace isdqn

@@ -1,0 +1,883 @@
+// iS-DQN Q-network on gfx950: forward over the 1+K shared heads, iterated Bellman target, squared TD
+// loss, backward and Adam.  Reference: slimdqn/networks/architectures/dqn.py:47-103 and
+// slimdqn/networks/isdqn.py:82-135.  Contractions run on the MFMA tile engine (gemm_core.h,
+// net_problems.h); the row-wise kernels below are the HBM-bound remainder.
+#include <stdarg.h>
+
+#include "net_plan.h"
+#include "net_problems.h"
+
+namespace isdqn {
+
+// =============================================================================================
+// Row-wise kernels
+// =============================================================================================
+
+// Dense layer tail (dqn.py:96-99): sum the split-K slabs, add the bias, LayerNorm over the row,
+// ReLU.  One workgroup per row; the row is staged in LDS between the two passes.
+__global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                         int64_t slab_stride, int rows, int F, int Fp,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int has_relu,
+                                                         float* __restrict__ act, float* __restrict__ z, int z_rows) {
+    extern __shared__ float s_row[];
+    __shared__ float s_red[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = tid; c < Fp; c += 256) {
+        float v = 0.f;
+        if (c < F) {
+            const float* p = slabs + (int64_t)row * Fp + c;
+            for (int s = 0; s < n_slabs; ++s) v += p[(int64_t)s * slab_stride];
+            v += bias[c];
+        }
+        s_row[c] = v;
+        s1 += v;
+        s2 += v * v;
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (gamma != nullptr) {
+        for (int off = 32; off > 0; off >>= 1) {
+            s1 += __shfl_xor(s1, off);
+            s2 += __shfl_xor(s2, off);
+        }
+        if ((tid & 63) == 0) {
+            s_red[0][tid >> 6] = s1;
+            s_red[1][tid >> 6] = s2;
+        }
+        __syncthreads();
+        s1 = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        s2 = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        mean = s1 / (float)F;
+        float var = fmaxf(s2 / (float)F - mean * mean, 0.f);
+        rstd = rsqrtf(var + 1e-6f);
+    }
+    for (int c = tid; c < Fp; c += 256) {
+        float v = s_row[c];  // written by this same thread
+        float y = v;
+        if (gamma != nullptr && c < F) y = (v - mean) * (rstd * gamma[c]) + beta[c];
+        if (has_relu) y = fmaxf(y, 0.f);
+        if (c >= F) y = 0.f;
+        act[(int64_t)row * Fp + c] = y;
+        if (row < z_rows) z[(int64_t)row * Fp + c] = v;
+    }
+}
+
+// LayerNorm + ReLU backward over the last axis (rows x C, C <= 4*TPR), TPR lanes per row, float4 per lane.
+//   xhat = (z-mean)*rstd ; y = xhat*gamma+beta ; dy = da*[y>0] ; dgamma += dy*xhat ; dbeta += dy
+//   g = dy*gamma ; dz = rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dbias += dz
+// Per-workgroup partial sums go to part[block][3][Cp] (deterministic; reduced by the Adam kernel).
+template <int TPR>
+__global__ __launch_bounds__(256) void ln_bwd_small_kernel(const float* __restrict__ da, const float* __restrict__ z,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int rows, int C, int Cp,
+                                                           float* __restrict__ dz, float* __restrict__ part) {
+    constexpr int RPB = 256 / TPR;
+    __shared__ float s_part[RPB][3][4 * TPR];
+    const int tid = threadIdx.x, grp = tid / TPR, sub = tid % TPR;
+    const int ch0 = sub * 4;
+    const bool lane_on = ch0 < Cp;
+    float ga[4], be[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bool ok = lane_on && (ch0 + r) < C;
+        ga[r] = (ok && gamma) ? gamma[ch0 + r] : 1.f;
+        be[r] = (ok && gamma) ? beta[ch0 + r] : 0.f;
+    }
+    float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0}, dbias[4] = {0, 0, 0, 0};
+    const float inv_c = 1.f / (float)C;
+    for (int row0 = blockIdx.x * RPB; row0 < rows; row0 += gridDim.x * RPB) {
+        const int row = row0 + grp;
+        const bool on = lane_on && row < rows;
+        float zv[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
+        if (on) {
+            float4 a = *reinterpret_cast<const float4*>(z + (int64_t)row * Cp + ch0);
+            float4 b = *reinterpret_cast<const float4*>(da + (int64_t)row * Cp + ch0);
+            zv[0] = a.x; zv[1] = a.y; zv[2] = a.z; zv[3] = a.w;
+            dv[0] = b.x; dv[1] = b.y; dv[2] = b.z; dv[3] = b.w;
+        }
+        float out[4];
+        if (gamma != nullptr) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bool ok = (ch0 + r) < C;
+                s1 += ok ? zv[r] : 0.f;
+                s2 += ok ? zv[r] * zv[r] : 0.f;
+            }
+#pragma unroll
+            for (int off = TPR / 2; off > 0; off >>= 1) {
+                s1 += __shfl_xor(s1, off);
+                s2 += __shfl_xor(s2, off);
+            }
+            float mean = s1 * inv_c;
+            float rstd = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + 1e-6f);
+            float xh[4], gg[4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bool ok = on && (ch0 + r) < C;
+                xh[r] = (zv[r] - mean) * rstd;
+                float y = xh[r] * ga[r] + be[r];
+                float dy = (ok && y > 0.f) ? dv[r] : 0.f;
+                dg[r] += dy * xh[r];
+                db[r] += dy;
+                gg[r] = dy * ga[r];
+                m1 += gg[r];
+                m2 += gg[r] * xh[r];
+            }
+#pragma unroll
+            for (int off = TPR / 2; off > 0; off >>= 1) {
+                m1 += __shfl_xor(m1, off);
+                m2 += __shfl_xor(m2, off);
+            }
+            m1 *= inv_c;
+            m2 *= inv_c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bool ok = on && (ch0 + r) < C;
+                out[r] = ok ? rstd * (gg[r] - m1 - xh[r] * m2) : 0.f;
+                dbias[r] += out[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bool ok = on && (ch0 + r) < C;
+                out[r] = (ok && zv[r] > 0.f) ? dv[r] : 0.f;
+                dbias[r] += out[r];
+            }
+        }
+        if (on) *reinterpret_cast<float4*>(dz + (int64_t)row * Cp + ch0) = float4{out[0], out[1], out[2], out[3]};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s_part[grp][0][ch0 + r] = dg[r];
+        s_part[grp][1][ch0 + r] = db[r];
+        s_part[grp][2][ch0 + r] = dbias[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * Cp; i += 256) {
+        int which = i / Cp, c = i % Cp;
+        float s = 0.f;
+        for (int g2 = 0; g2 < RPB; ++g2) s += s_part[g2][which][c];
+        part[((int64_t)blockIdx.x * 3 + which) * Cp + c] = s;
+    }
+}
+
+// Same, wide rows (dense layers): one workgroup per row at a time, columns strided over the threads.
+constexpr int LN_WIDE_MAX_COLS = 16;  // per thread: widths up to 4096
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restrict__ da, const float* __restrict__ z,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int rows, int C, int Cp,
+                                                          float* __restrict__ dz, float* __restrict__ part) {
+    __shared__ float s_red[4][4];
+    const int tid = threadIdx.x;
+    float dg[LN_WIDE_MAX_COLS], db[LN_WIDE_MAX_COLS], dbias[LN_WIDE_MAX_COLS];
+#pragma unroll
+    for (int i = 0; i < LN_WIDE_MAX_COLS; ++i) dg[i] = db[i] = dbias[i] = 0.f;
+    const float inv_c = 1.f / (float)C;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* zr = z + (int64_t)row * Cp;
+        const float* dr = da + (int64_t)row * Cp;
+        float* outr = dz + (int64_t)row * Cp;
+        if (gamma != nullptr) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_WIDE_MAX_COLS; ++i) {
+                int c = tid + i * 256;
+                if (c < C) {
+                    float v = zr[c];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                s1 += __shfl_xor(s1, off);
+                s2 += __shfl_xor(s2, off);
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) { s_red[0][tid >> 6] = s1; s_red[1][tid >> 6] = s2; }
+            __syncthreads();
+            s1 = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+            s2 = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+            float mean = s1 * inv_c;
+            float rstd = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + 1e-6f);
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_WIDE_MAX_COLS; ++i) {
+                int c = tid + i * 256;
+                if (c < C) {
+                    float xh = (zr[c] - mean) * rstd;
+                    float y = xh * gamma[c] + beta[c];
+                    float dy = y > 0.f ? dr[c] : 0.f;
+                    dg[i] += dy * xh;
+                    db[i] += dy;
+                    float g2 = dy * gamma[c];
+                    m1 += g2;
+                    m2 += g2 * xh;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                m1 += __shfl_xor(m1, off);
+                m2 += __shfl_xor(m2, off);
+            }
+            if ((tid & 63) == 0) { s_red[2][tid >> 6] = m1; s_red[3][tid >> 6] = m2; }
+            __syncthreads();
+            m1 = (s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3]) * inv_c;
+            m2 = (s_red[3][0] + s_red[3][1] + s_red[3][2] + s_red[3][3]) * inv_c;
+#pragma unroll
+            for (int i = 0; i < LN_WIDE_MAX_COLS; ++i) {
+                int c = tid + i * 256;
+                if (c < Cp) {
+                    float o = 0.f;
+                    if (c < C) {
+                        float xh = (zr[c] - mean) * rstd;
+                        float y = xh * gamma[c] + beta[c];
+                        float dy = y > 0.f ? dr[c] : 0.f;
+                        o = rstd * (dy * gamma[c] - m1 - xh * m2);
+                    }
+                    dbias[i] += o;
+                    outr[c] = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < LN_WIDE_MAX_COLS; ++i) {
+                int c = tid + i * 256;
+                if (c < Cp) {
+                    float o = (c < C && zr[c] > 0.f) ? dr[c] : 0.f;
+                    dbias[i] += o;
+                    outr[c] = o;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_WIDE_MAX_COLS; ++i) {
+        int c = tid + i * 256;
+        if (c < Cp) {
+            float* p = part + (int64_t)blockIdx.x * 3 * Cp;
+            p[c] = dg[i];
+            p[Cp + c] = db[i];
+            p[2 * Cp + c] = dbias[i];
+        }
+    }
+}
+
+// Iterated Bellman target + squared TD loss (isdqn.py:92-109), one workgroup.
+//   q_k(s,a) from head 1+k of the online rows, target_k = r + (1-terminal)*gamma^n*max_a' Q_k(s',a')
+//   from head k of the next-state rows (same parameters, stop-gradient), loss_k = mean_b td.
+// Also emits dL/dq (dout), its column sums (head bias gradient), priorities and bumps the Adam step.
+__global__ __launch_bounds__(1024) void head_loss_kernel(const float* __restrict__ q, int B, int K, int A, int nha_p,
+                                                         const int* __restrict__ action,
+                                                         const float* __restrict__ reward,
+                                                         const uint8_t* __restrict__ terminal, float gamma_n,
+                                                         float* __restrict__ dout, float* __restrict__ q_values,
+                                                         float* __restrict__ targets, float* __restrict__ losses,
+                                                         double* __restrict__ priorities, float* __restrict__ dbh,
+                                                         int* adam_count) {
+    __shared__ float s_red[16];
+    const int tid = threadIdx.x;
+    constexpr int MAXB = 4;  // B <= 4096
+    float td_sum[MAXB] = {0, 0, 0, 0};
+    if (dout != nullptr)
+        for (int i = tid; i < B * nha_p; i += 1024) dout[i] = 0.f;
+    __syncthreads();
+    const float inv_b = 1.f / (float)B;
+    for (int k = 0; k < K; ++k) {
+        float local = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXB; ++it) {
+            int b = tid + it * 1024;
+            if (b < B) {
+                int a = action[b];
+                float qv = q[(int64_t)b * nha_p + (1 + k) * A + a];
+                const float* nq = q + (int64_t)(B + b) * nha_p + k * A;
+                float mx = nq[0];
+                for (int j = 1; j < A; ++j) mx = fmaxf(mx, nq[j]);
+                float tg = reward[b] + (1.f - (float)terminal[b]) * gamma_n * mx;
+                float d = qv - tg;
+                float td = d * d;
+                if (q_values) q_values[(int64_t)b * K + k] = qv;
+                if (targets) targets[(int64_t)b * K + k] = tg;
+                if (dout) dout[(int64_t)b * nha_p + (1 + k) * A + a] = 2.f * d * inv_b;
+                td_sum[it] += td;
+                local += td;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+        __syncthreads();
+        if ((tid & 63) == 0) s_red[tid >> 6] = local;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < 16; ++w) s += s_red[w];
+            losses[k] = s * inv_b;
+        }
+    }
+    if (priorities != nullptr) {
+#pragma unroll
+        for (int it = 0; it < MAXB; ++it) {
+            int b = tid + it * 1024;
+            if (b < B) priorities[b] = sqrt((double)(td_sum[it] / (float)K) + 1e-10);
+        }
+    }
+    __syncthreads();
+    if (dbh != nullptr && dout != nullptr) {
+        for (int c = tid; c < nha_p; c += 1024) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += dout[(int64_t)b * nha_p + c];
+            dbh[c] = s;
+        }
+    }
+    if (adam_count != nullptr && tid == 0) *adam_count = *adam_count + 1;
+}
+
+// Adam (optax.adam, isdqn.py:46, 85-86) over the flat parameter buffer; the gradient of every
+// tensor is the sum of its slabs (split-K partials / LayerNorm-backward partials), so gradients
+// are reduced here and never stored in reduced form.
+struct AdamEntry {
+    int64_t p_off, size, slab_stride;
+    const float* g;
+    int n_slabs, block_start;
+};
+constexpr int ADAM_MAX_ENTRIES = 4 * MAX_LAYERS;
+struct AdamTable {
+    AdamEntry e[ADAM_MAX_ENTRIES];
+    int n, total_blocks;
+};
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* __restrict__ p, float* __restrict__ m,
+                                                   float* __restrict__ v, const int* __restrict__ count, float lr,
+                                                   float b1, float b2, float eps, float* __restrict__ grad_out) {
+    __shared__ float s_c[2];
+    int e = 0;
+    while (e + 1 < tab.n && (int)blockIdx.x >= tab.e[e + 1].block_start) ++e;
+    const AdamEntry en = tab.e[e];
+    if (threadIdx.x == 0) {
+        double t = (double)(*count);
+        s_c[0] = (float)(1.0 - pow((double)b1, t));
+        s_c[1] = (float)(1.0 - pow((double)b2, t));
+    }
+    __syncthreads();
+    const float c1 = s_c[0], c2 = s_c[1];
+    int64_t i = ((int64_t)(blockIdx.x - en.block_start) * 256 + threadIdx.x) * 4;
+    if (i >= en.size) return;
+    float4 g = *reinterpret_cast<const float4*>(en.g + i);
+    for (int s = 1; s < en.n_slabs; ++s) {
+        float4 h = *reinterpret_cast<const float4*>(en.g + (int64_t)s * en.slab_stride + i);
+        g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
+    }
+    const int64_t o = en.p_off + i;
+    if (grad_out != nullptr) *reinterpret_cast<float4*>(grad_out + o) = g;
+    float4 pm = *reinterpret_cast<float4*>(m + o), pv = *reinterpret_cast<float4*>(v + o);
+    float4 pp = *reinterpret_cast<float4*>(p + o);
+    float* gp = &g.x; float* mp = &pm.x; float* vp = &pv.x; float* xp = &pp.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float mm = b1 * mp[r] + (1.f - b1) * gp[r];
+        float vv = b2 * vp[r] + (1.f - b2) * gp[r] * gp[r];
+        mp[r] = mm;
+        vp[r] = vv;
+        xp[r] = xp[r] - lr * ((mm / c1) / (sqrtf(vv / c2) + eps));
+    }
+    *reinterpret_cast<float4*>(m + o) = pm;
+    *reinterpret_cast<float4*>(v + o) = pv;
+    *reinterpret_cast<float4*>(p + o) = pp;
+}
+
+// shift_params (isdqn.py:111-125): rows [0, nha-A) <- rows [A, nha) of the last Dense ([out][in] layout).
+__global__ __launch_bounds__(256) void shift_kernel(float* __restrict__ w, float* __restrict__ bias, int nha, int A,
+                                                    int in_p) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < in_p)
+        for (int r = 0; r + A < nha; ++r) w[(int64_t)r * in_p + f] = w[(int64_t)(r + A) * in_p + f];
+    if (f == in_p)
+        for (int r = 0; r + A < nha; ++r) bias[r] = bias[r + A];
+}
+
+// best_action (isdqn.py:127-135): first argmax over the actions of head 1+idx.
+__global__ void argmax_kernel(const float* __restrict__ q, int A, int head, int* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float* r = q + head * A;
+        int best = 0;
+        for (int a = 1; a < A; ++a)
+            if (r[a] > r[best]) best = a;
+        *out = best;
+    }
+}
+
+// =============================================================================================
+// Host orchestration
+// =============================================================================================
+static ConvGeom conv_geom(const Layer& l) {
+    ConvGeom g;
+    g.hin = l.hin; g.win = l.win; g.cin_p = l.cin_p; g.hout = l.hout; g.wout = l.wout;
+    g.cout = l.cout; g.cout_p = l.cout_p; g.ksz = l.ksz; g.stride = l.stride; g.pad = l.pad;
+    g.npix = l.npix; g.K = l.K;
+    g.d_npix = FastDiv(l.npix); g.d_wout = FastDiv(l.wout); g.d_cinp = FastDiv(l.cin_p);
+    g.d_ksz = FastDiv(l.ksz); g.d_coutp = FastDiv(l.cout_p);
+    return g;
+}
+
+struct NetInput {
+    const uint8_t* frames; int64_t frame_stride; const int* frame_ids; int paired_B;  // cnn
+    const float* obs; const float* obs2; int obs_split;                             // fc
+};
+
+template <int BM, int PASSES, bool U8>
+static int launch_conv_fwd(const Layer& l, const float* params, const NetInput& in, const float* act_in, int n_img,
+                           int z_img, float* act, float* z, hipStream_t st) {
+    ConvFwd<BM, PASSES, U8> p;
+    p.g = conv_geom(l);
+    p.W = MatSrc{params + l.w_off, l.K, l.cout_p, l.K, 1};
+    p.in = act_in;
+    p.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win};
+    p.bias = params + l.b_off;
+    p.gamma = l.has_ln ? params + l.g_off : nullptr;
+    p.beta = l.has_ln ? params + l.be_off : nullptr;
+    p.scale = U8 ? (1.0f / 255.0f) : 1.0f;
+    p.act = act; p.z = z;
+    p.n_pix_total = n_img * l.npix;
+    p.z_pix = z_img * l.npix;
+    return launch_gemm(p, ceil_div(p.n_pix_total, 128), st);
+}
+
+static int conv_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int n_img,
+                    int z_img, float* act, float* z, hipStream_t st) {
+    const bool small = l.cout_p <= 32;
+    if (l.is_u8) {
+        if (x3) return small ? launch_conv_fwd<32, 2, true>(l, params, in, act_in, n_img, z_img, act, z, st)
+                             : launch_conv_fwd<64, 2, true>(l, params, in, act_in, n_img, z_img, act, z, st);
+        return small ? launch_conv_fwd<32, 1, true>(l, params, in, act_in, n_img, z_img, act, z, st)
+                     : launch_conv_fwd<64, 1, true>(l, params, in, act_in, n_img, z_img, act, z, st);
+    }
+    if (x3) return small ? launch_conv_fwd<32, 3, false>(l, params, in, act_in, n_img, z_img, act, z, st)
+                         : launch_conv_fwd<64, 3, false>(l, params, in, act_in, n_img, z_img, act, z, st);
+    return small ? launch_conv_fwd<32, 1, false>(l, params, in, act_in, n_img, z_img, act, z, st)
+                 : launch_conv_fwd<64, 1, false>(l, params, in, act_in, n_img, z_img, act, z, st);
+}
+
+// C[split][M][N] = A . B^T over row-major sources.  a_tr/b_tr: the operand is stored [K][rows].
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, int PASSES>
+static int launch_plain(const MatSrc& A, const float* A2, int a_split, const MatSrc& B, float* C, int ldc, int M,
+                        int N, int K, int splits, int64_t slab_stride, hipStream_t st) {
+    PlainGemm<BM, BN, WM, WN, ATR, BTR, PASSES> p;
+    p.A = A; p.B = B; p.A2 = A2; p.a_split = a_split; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    p.tiles_m = ceil_div(M, BM); p.tiles_n = ceil_div(N, BN);
+    int ksteps = ceil_div(K, GEMM_BK);
+    if (splits < 1) splits = 1;
+    if (splits > ksteps) splits = ksteps;
+    p.steps_per_split = ceil_div(ksteps, splits);
+    p.splits = ceil_div(ksteps, p.steps_per_split);
+    p.slab_stride = slab_stride;
+    return launch_gemm(p, p.tiles_m * p.tiles_n * p.splits, st);
+}
+// number of slabs launch_plain will actually write for (K, splits)
+static int effective_splits(int K, int splits) {
+    int ksteps = ceil_div(K, GEMM_BK);
+    if (splits < 1) splits = 1;
+    if (splits > ksteps) splits = ksteps;
+    int sps = ceil_div(ksteps, splits);
+    return ceil_div(ksteps, sps);
+}
+
+template <bool ATR, bool BTR>
+static int plain_big(bool x3, const MatSrc& A, const float* A2, int a_split, const MatSrc& B, float* C, int ldc,
+                     int M, int N, int K, int splits, int64_t slab_stride, hipStream_t st) {
+    if (x3) return launch_plain<128, 128, 2, 2, ATR, BTR, 3>(A, A2, a_split, B, C, ldc, M, N, K, splits, slab_stride, st);
+    return launch_plain<128, 128, 2, 2, ATR, BTR, 1>(A, A2, a_split, B, C, ldc, M, N, K, splits, slab_stride, st);
+}
+
+static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int rows,
+                     int z_rows, float* slab, float* act, float* z, hipStream_t st) {
+    MatSrc A, B;
+    const float* A2 = nullptr;
+    int a_split = 0;
+    if (l.in_unpadded_ld) {  // fc first layer: caller's [rows][obs] matrices
+        A = MatSrc{in.obs, l.in_unpadded_ld, rows, l.in_f, 0};
+        if (in.obs2) { A2 = in.obs2; a_split = in.obs_split; }
+    } else {
+        A = MatSrc{act_in, l.in_p, rows, l.in_p, 1};
+    }
+    B = MatSrc{params + l.w_off, l.in_p, l.out_f, l.in_p, 1};
+    const int64_t slab_stride = (int64_t)rows * l.out_p;
+    int rc = plain_big<false, false>(x3, A, A2, a_split, B, slab, l.out_p, rows, l.out_f, l.K, l.fwd_splits,
+                                     slab_stride, st);
+    if (rc) return rc;
+    int ns = effective_splits(l.K, l.fwd_splits);
+    hipLaunchKernelGGL(dense_post_kernel, dim3(rows), dim3(256), l.out_p * sizeof(float), st, slab, ns, slab_stride,
+                       rows, l.out_f, l.out_p, params + l.b_off, l.has_ln ? params + l.g_off : nullptr,
+                       l.has_ln ? params + l.be_off : nullptr, l.has_relu, act, z, z_rows);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
+// forward over n_img images; hidden activations -> ws act regions, head output -> q_out [n_img][nha_p]
+static int net_forward(const Plan& P, bool x3, const float* params, const NetInput& in, int n_img, int z_img,
+                       float* ws, float* q_out, hipStream_t st) {
+    const float* prev = nullptr;
+    for (int i = 0; i < P.n_layers; ++i) {
+        const Layer& l = P.L[i];
+        float* act = l.is_head ? q_out : ws + l.act_off;
+        float* z = l.is_head ? nullptr : ws + l.z_off;
+        int rc;
+        if (l.kind == 0)
+            rc = conv_fwd(l, x3, params, in, prev, n_img, z_img, act, z, st);
+        else
+            rc = dense_fwd(l, x3, params, in, prev, n_img, l.is_head ? 0 : z_img, ws + P.slab_off, act, z, st);
+        if (rc) return rc;
+        prev = act;
+    }
+    return ISDQN_OK;
+}
+
+static int ln_bwd(const Layer& l, const float* params, const float* da, const float* z, int rows, float* dz,
+                  float* part, int* n_blocks_out, hipStream_t st) {
+    const float* gamma = l.has_ln ? params + l.g_off : nullptr;
+    const float* beta = l.has_ln ? params + l.be_off : nullptr;
+    const int C = l.out_f, Cp = l.out_p;
+    int nb;
+#define LAUNCH_SMALL(TPR)                                                                                          \
+    do {                                                                                                           \
+        nb = ceil_div(rows, 256 / TPR);                                                                            \
+        if (nb > LN_MAX_BLOCKS) nb = LN_MAX_BLOCKS;                                                                \
+        hipLaunchKernelGGL(ln_bwd_small_kernel<TPR>, dim3(nb), dim3(256), 0, st, da, z, gamma, beta, rows, C, Cp,  \
+                           dz, part);                                                                              \
+    } while (0)
+    if (Cp <= 32) LAUNCH_SMALL(8);
+    else if (Cp <= 64) LAUNCH_SMALL(16);
+    else if (Cp <= 128) LAUNCH_SMALL(32);
+    else if (Cp <= 256) LAUNCH_SMALL(64);
+    else {
+        ISDQN_REQUIRE(Cp <= 256 * LN_WIDE_MAX_COLS, ISDQN_ERR_UNSUPPORTED, "hidden dense width above 4096");
+        nb = rows < LN_MAX_BLOCKS ? rows : LN_MAX_BLOCKS;
+        hipLaunchKernelGGL(ln_bwd_wide_kernel, dim3(nb), dim3(256), 0, st, da, z, gamma, beta, rows, C, Cp, dz, part);
+    }
+#undef LAUNCH_SMALL
+    ISDQN_HIP_CHECK(hipGetLastError());
+    *n_blocks_out = nb;
+    return ISDQN_OK;
+}
+
+template <int BM, int PASSES>
+static int launch_conv_dgrad(const Layer& l, const float* params, const float* dz, float* da, int n_img,
+                             hipStream_t st) {
+    ConvDgrad<BM, PASSES> p;
+    p.g = conv_geom(l);
+    p.W = params + l.w_off;
+    p.dz = dz; p.da = da; p.n_img = n_img;
+    p.T = l.ksz / l.stride;
+    p.Kc = p.T * p.T * l.cout_p;
+    p.n_classes = l.stride * l.stride;
+    int acc = 0;
+    for (int c = 0; c < p.n_classes; ++c) {
+        int cy = c / l.stride, cx = c % l.stride;
+        int Ha = (l.hin - cy + l.stride - 1) / l.stride, Wb = (l.win - cx + l.stride - 1) / l.stride;
+        p.tile_start[c] = acc;
+        p.cls_d_hw[c] = FastDiv((uint32_t)(Ha * Wb));
+        p.cls_d_w[c] = FastDiv((uint32_t)Wb);
+        acc += ceil_div(n_img * Ha * Wb, 128);
+    }
+    p.tile_start[p.n_classes] = acc;
+    return launch_gemm(p, acc, st);
+}
+
+template <int PASSES, bool U8>
+static int launch_conv_wgrad(const Layer& l, const NetInput& in, const float* act_in, const float* dz, float* slabs,
+                             int n_img, hipStream_t st) {
+    ConvWgrad<PASSES, U8> p;
+    p.g = conv_geom(l);
+    p.n_pix = n_img * l.npix;
+    p.DZ = MatSrc{dz, l.cout_p, p.n_pix, l.cout_p, 1};
+    p.in = act_in;
+    p.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win};
+    p.slabs = slabs;
+    p.scale = U8 ? (1.0f / 255.0f) : 1.0f;
+    p.tiles_n = ceil_div(l.K, 64);
+    int ksteps = ceil_div(p.n_pix, GEMM_BK);
+    p.steps_per_split = ceil_div(ksteps, l.gw_slabs);
+    p.splits = ceil_div(ksteps, p.steps_per_split);
+    return launch_gemm(p, p.tiles_n * p.splits, st);
+}
+static int conv_wgrad_slabs(const Layer& l, int n_img) {
+    int ksteps = ceil_div(n_img * l.npix, GEMM_BK);
+    int sps = ceil_div(ksteps, l.gw_slabs);
+    return ceil_div(ksteps, sps);
+}
+
+}  // namespace isdqn
+
+using namespace isdqn;
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" int isdqn_net_param_layout(const isdqn_net_config* cfg, int64_t* n_param_floats, isdqn_tensor_info* infos,
+                                      int32_t max_infos, int32_t* n_infos) {
+    Plan P;
+    int rc = build_plan(cfg, P);
+    if (rc) return rc;
+    if (n_param_floats) *n_param_floats = P.n_params;
+    int n = 0;
+    auto add = [&](const char* mod, const char* leaf, int64_t off, int64_t size, int kind, int layer, int ndim,
+                   int s0, int s1, int s2, int s3, int d0, int d1, int d2) {
+        if (infos && n < max_infos) {
+            isdqn_tensor_info& t = infos[n];
+            memset(&t, 0, sizeof(t));
+            snprintf(t.name, sizeof(t.name), "%s/%s", mod, leaf);
+            t.offset = off; t.size = size; t.kind = kind; t.layer = layer; t.ndim = ndim;
+            t.flax_shape[0] = s0; t.flax_shape[1] = s1; t.flax_shape[2] = s2; t.flax_shape[3] = s3;
+            t.dims[0] = d0; t.dims[1] = d1; t.dims[2] = d2; t.dims[3] = 0;
+        }
+        ++n;
+    };
+    for (int i = 0; i < P.n_layers; ++i) {
+        const Layer& l = P.L[i];
+        if (l.kind == 0) {
+            add(l.name, "kernel", l.w_off, l.w_size, 0, i, 4, l.ksz, l.ksz, l.cin, l.cout, l.cout_p, l.is_u8 ? l.cin : l.taps,
+                l.is_u8 ? 64 : l.cin_p);
+        } else {
+            add(l.name, "kernel", l.w_off, l.w_size, 1, i, 2, l.in_f, l.out_f, 0, 0, l.out_p, l.in_p, 0);
+        }
+        add(l.name, "bias", l.b_off, l.out_p, 2, i, 1, l.out_f, 0, 0, 0, l.out_p, 0, 0);
+        if (l.has_ln) {
+            add(l.ln_name, "scale", l.g_off, l.out_p, 3, i, 1, l.out_f, 0, 0, 0, l.out_p, 0, 0);
+            add(l.ln_name, "bias", l.be_off, l.out_p, 4, i, 1, l.out_f, 0, 0, 0, l.out_p, 0, 0);
+        }
+    }
+    if (n_infos) *n_infos = n;
+    return ISDQN_OK;
+}
+
+extern "C" int isdqn_net_workspace_bytes(const isdqn_net_config* cfg, int64_t* bytes) {
+    Plan P;
+    int rc = build_plan(cfg, P);
+    if (rc) return rc;
+    ISDQN_REQUIRE(bytes != nullptr, ISDQN_ERR_ARG, "null pointer");
+    *bytes = P.ws_bytes;
+    return ISDQN_OK;
+}
+
+extern "C" int isdqn_net_workspace_region(const isdqn_net_config* cfg, const char* name, int64_t* offset_bytes,
+                                          int64_t* size_bytes) {
+    Plan P;
+    int rc = build_plan(cfg, P);
+    if (rc) return rc;
+    ISDQN_REQUIRE(name != nullptr, ISDQN_ERR_ARG, "null name");
+    for (auto& r : P.regions)
+        if (r.first == name) {
+            if (offset_bytes) *offset_bytes = r.second.first;
+            if (size_bytes) *size_bytes = r.second.second;
+            return ISDQN_OK;
+        }
+    set_last_error("unknown workspace region '%s'", name);
+    return ISDQN_ERR_ARG;
+}
+
+static int check_input(const isdqn_net_config* cfg, const uint8_t* frames, int64_t frame_stride,
+                       const int32_t* frame_ids, const float* obs) {
+    if (cfg->arch == ISDQN_ARCH_CNN) {
+        ISDQN_REQUIRE(frames && frame_ids, ISDQN_ERR_ARG, "cnn needs frames and frame_ids");
+        ISDQN_REQUIRE(frame_stride >= (int64_t)cfg->obs_h * cfg->obs_w, ISDQN_ERR_SHAPE, "frame_stride < h*w");
+    } else {
+        ISDQN_REQUIRE(obs != nullptr, ISDQN_ERR_ARG, "fc needs obs");
+    }
+    return ISDQN_OK;
+}
+
+extern "C" int isdqn_net_forward(const isdqn_net_config* cfg, const float* params, const uint8_t* frames,
+                                 int64_t frame_stride, const int32_t* frame_ids, const float* obs, int32_t n_rows,
+                                 float* q_out, void* workspace, void* stream) {
+    Plan P;
+    int rc = build_plan(cfg, P);
+    if (rc) return rc;
+    ISDQN_REQUIRE(params && q_out && workspace, ISDQN_ERR_ARG, "null pointer");
+    ISDQN_REQUIRE(n_rows >= 1 && n_rows <= P.N2, ISDQN_ERR_SHAPE, "n_rows must be in [1, 2*batch_size]");
+    rc = check_input(cfg, frames, frame_stride, frame_ids, obs);
+    if (rc) return rc;
+    NetInput in{frames, frame_stride, frame_ids, 0, obs, nullptr, 0};
+    float* ws = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    rc = net_forward(P, cfg->precision == ISDQN_PRECISION_BF16X3, params, in, n_rows, 0, ws, ws + P.q_off, st);
+    if (rc) return rc;
+    // q_out is the unpadded (n_rows, nha) view
+    ISDQN_HIP_CHECK(hipMemcpy2DAsync(q_out, (size_t)P.nha * 4, ws + P.q_off, (size_t)P.nha_p * 4, (size_t)P.nha * 4,
+                                     n_rows, hipMemcpyDeviceToDevice, st));
+    return ISDQN_OK;
+}
+
+static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v, int32_t* adam_count,
+                         const isdqn_batch* batch, float* losses, float* q_values, float* targets, double* priorities,
+                         void* workspace, void* stream, bool learn, float* grad_out) {
+    Plan P;
+    int rc = build_plan(cfg, P);
+    if (rc) return rc;
+    ISDQN_REQUIRE(params && batch && losses && workspace, ISDQN_ERR_ARG, "null pointer");
+    ISDQN_REQUIRE(batch->B == P.B, ISDQN_ERR_SHAPE, "batch->B != cfg->batch_size");
+    ISDQN_REQUIRE(batch->action && batch->reward && batch->terminal, ISDQN_ERR_ARG, "null batch field");
+    rc = check_input(cfg, batch->frames, batch->frame_stride, batch->frame_ids, batch->state);
+    if (rc) return rc;
+    if (cfg->arch == ISDQN_ARCH_FC) ISDQN_REQUIRE(batch->next_state != nullptr, ISDQN_ERR_ARG, "fc needs next_state");
+    if (learn) ISDQN_REQUIRE(adam_m && adam_v && adam_count, ISDQN_ERR_ARG, "null optimizer state");
+    const bool x3 = cfg->precision == ISDQN_PRECISION_BF16X3;
+    const int B = P.B, K = P.n_heads - 1;
+    float* ws = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    NetInput in{batch->frames, batch->frame_stride, batch->frame_ids, B, batch->state, batch->next_state, B};
+
+    // ---- forward on concat(state, next_state) (isdqn.py:95) ----
+    rc = net_forward(P, x3, params, in, P.N2, B, ws, ws + P.q_off, st);
+    if (rc) return rc;
+
+    // ---- targets, loss, dL/dq ----
+    float* qv = q_values ? q_values : ws + P.qv_off;
+    float* tg = targets ? targets : ws + P.tg_off;
+    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(1024), 0, st, ws + P.q_off, B, K, P.n_actions, P.nha_p,
+                       batch->action, batch->reward, batch->terminal, cfg->gamma_n, learn ? ws + P.dout_off : nullptr,
+                       qv, tg, losses, priorities, learn ? ws + P.dbh_off : nullptr, learn ? adam_count : nullptr);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    if (!learn) return ISDQN_OK;
+
+    // ---- backward (online rows only: the next-state half has a zero cotangent, isdqn.py:99) ----
+    AdamTable tab;
+    tab.n = 0;
+    int blocks = 0;
+    auto add_entry = [&](int64_t p_off, int64_t size, const float* g, int n_slabs, int64_t stride) {
+        AdamEntry& e = tab.e[tab.n++];
+        e.p_off = p_off; e.size = size; e.g = g; e.n_slabs = n_slabs; e.slab_stride = stride;
+        e.block_start = blocks;
+        blocks += (int)((size + 1023) / 1024);
+    };
+    const float* dz_cur = ws + P.dout_off;  // gradient w.r.t. the current layer's pre-activation output
+    int dz_ld = P.nha_p;
+    for (int i = P.n_layers - 1; i >= 0; --i) {
+        const Layer& l = P.L[i];
+        const float* act_in = i > 0 ? ws + P.L[i - 1].act_off : nullptr;
+        if (!l.is_head) {
+            // da (w.r.t. this layer's activation) was left in ws+da_off by layer i+1's data-gradient
+            int rows = l.kind == 0 ? B * l.npix : B;
+            int nb = 0;
+            rc = ln_bwd(l, params, ws + P.da_off, ws + l.z_off, rows, ws + l.dz_off, ws + l.part_off, &nb, st);
+            if (rc) return rc;
+            dz_cur = ws + l.dz_off;
+            dz_ld = l.out_p;
+            if (l.has_ln) {
+                add_entry(l.g_off, l.out_p, ws + l.part_off, nb, 3 * (int64_t)l.out_p);
+                add_entry(l.be_off, l.out_p, ws + l.part_off + l.out_p, nb, 3 * (int64_t)l.out_p);
+            }
+            add_entry(l.b_off, l.out_p, ws + l.part_off + 2 * l.out_p, nb, 3 * (int64_t)l.out_p);
+        } else {
+            add_entry(l.b_off, l.out_p, ws + P.dbh_off, 1, 0);
+        }
+        // weight gradient -> slabs
+        int w_slabs;
+        if (l.kind == 0) {
+            if (l.is_u8) rc = x3 ? launch_conv_wgrad<2, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, st)
+                                 : launch_conv_wgrad<1, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, st);
+            else rc = x3 ? launch_conv_wgrad<3, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, st)
+                         : launch_conv_wgrad<1, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, st);
+            w_slabs = conv_wgrad_slabs(l, B);
+        } else {
+            // dW[out][in_p] = sum_b dz[b][out] * a[b][in_p] : both operands stored [K = b][rows]
+            MatSrc A{dz_cur, dz_ld, B, l.out_p, 1};
+            MatSrc Bm = l.in_unpadded_ld ? MatSrc{in.obs, l.in_unpadded_ld, B, l.in_f, 0}
+                                         : MatSrc{act_in, l.in_p, B, l.in_p, 1};
+            rc = plain_big<true, true>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B, l.gw_slabs,
+                                       l.w_size, st);
+            w_slabs = effective_splits(B, l.gw_slabs);
+        }
+        if (rc) return rc;
+        add_entry(l.w_off, l.w_size, ws + l.gw_off, w_slabs, l.w_size);
+        // data gradient for the layer below
+        if (i > 0) {
+            if (l.kind == 0) {
+                const bool small = l.cin_p <= 32;
+                if (x3) rc = small ? launch_conv_dgrad<32, 3>(l, params, dz_cur, ws + P.da_off, B, st)
+                                   : launch_conv_dgrad<64, 3>(l, params, dz_cur, ws + P.da_off, B, st);
+                else rc = small ? launch_conv_dgrad<32, 1>(l, params, dz_cur, ws + P.da_off, B, st)
+                                : launch_conv_dgrad<64, 1>(l, params, dz_cur, ws + P.da_off, B, st);
+            } else {
+                // da[b][in_p] = sum_o dz[b][o] * W[o][in_p]
+                MatSrc A{dz_cur, dz_ld, B, l.out_p, 1};
+                MatSrc Bm{params + l.w_off, l.in_p, l.out_f, l.in_p, 1};
+                rc = plain_big<false, true>(x3, A, nullptr, 0, Bm, ws + P.da_off, l.in_p, B, l.in_p, l.out_p, 1, 0, st);
+            }
+            if (rc) return rc;
+        }
+    }
+    tab.total_blocks = blocks;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, tab, params, adam_m, adam_v, adam_count,
+                       cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps, grad_out);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
+extern "C" int isdqn_net_learn_on_batch(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v,
+                                        int32_t* adam_count, const isdqn_batch* batch, float* losses, float* q_values,
+                                        float* targets, double* priorities, void* workspace, void* stream) {
+    return learn_or_loss(cfg, params, adam_m, adam_v, adam_count, batch, losses, q_values, targets, priorities,
+                         workspace, stream, true, nullptr);
+}
+
+// Test hook (not in the public header): learn_on_batch that also writes the reduced gradient (internal layout).
+extern "C" int isdqn_net_learn_on_batch_debug(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v,
+                                              int32_t* adam_count, const isdqn_batch* batch, float* losses,
+                                              float* q_values, float* targets, double* priorities, void* workspace,
+                                              void* stream, float* grad_out) {
+    return learn_or_loss(cfg, params, adam_m, adam_v, adam_count, batch, losses, q_values, targets, priorities,
+                         workspace, stream, true, grad_out);
+}
+
+extern "C" int isdqn_net_loss_on_batch(const isdqn_net_config* cfg, const float* params, const isdqn_batch* batch,
+                                       float* losses, float* q_values, float* targets, void* workspace, void* stream) {
+    return learn_or_loss(cfg, const_cast<float*>(params), nullptr, nullptr, nullptr, batch, losses, q_values, targets,
+                         nullptr, workspace, stream, false, nullptr);
+}
+
+extern "C" int isdqn_net_shift_params(const isdqn_net_config* cfg, float* params, void* stream) {
+    Plan P;
+    int rc = build_plan(cfg, P);
+    if (rc) return rc;
+    ISDQN_REQUIRE(params != nullptr, ISDQN_ERR_ARG, "null pointer");
+    const Layer& l = P.L[P.n_layers - 1];
+    hipLaunchKernelGGL(shift_kernel, dim3(ceil_div(l.in_p + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                       params + l.w_off, params + l.b_off, P.nha, P.n_actions, l.in_p);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
+extern "C" int isdqn_net_best_action(const isdqn_net_config* cfg, const float* params, const uint8_t* frames,
+                                     int64_t frame_stride, const int32_t* frame_ids, const float* obs,
+                                     int32_t idx_network, int32_t* out_action, void* workspace, void* stream) {
+    Plan P;
+    int rc = build_plan(cfg, P);
+    if (rc) return rc;
+    ISDQN_REQUIRE(params && out_action && workspace, ISDQN_ERR_ARG, "null pointer");
+    ISDQN_REQUIRE(idx_network >= 0 && idx_network < P.n_heads - 1, ISDQN_ERR_ARG, "idx_network out of range");
+    rc = check_input(cfg, frames, frame_stride, frame_ids, obs);
+    if (rc) return rc;
+    NetInput in{frames, frame_stride, frame_ids, 0, obs, nullptr, 0};
+    float* ws = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    rc = net_forward(P, cfg->precision == ISDQN_PRECISION_BF16X3, params, in, 1, 0, ws, ws + P.q_off, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(64), 0, st, ws + P.q_off, P.n_actions, 1 + idx_network, out_action);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
+extern "C" int isdqn_selftest_gemm(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K,
+                                   int32_t a_tr, int32_t b_tr, int32_t precision, int32_t split_k, void* stream) {
+    ISDQN_REQUIRE(A && B && C, ISDQN_ERR_ARG, "null pointer");
+    ISDQN_REQUIRE(M > 0 && N > 0 && K > 0, ISDQN_ERR_SHAPE, "bad shape");
+    const bool x3 = precision == ISDQN_PRECISION_BF16X3;
+    hipStream_t st = (hipStream_t)stream;
+    // ROW operand: [rows][K] ; TR operand: [K][rows].  No alignment promises (self-test shapes are arbitrary).
+    MatSrc a = a_tr ? MatSrc{A, M, K, M, 0} : MatSrc{A, K, M, K, 0};
+    MatSrc b = b_tr ? MatSrc{B, N, K, N, 0} : MatSrc{B, K, N, K, 0};
+    const int64_t slab = (int64_t)M * N;
+    if (!a_tr && !b_tr) return plain_big<false, false>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
+    if (!a_tr && b_tr) return plain_big<false, true>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
+    if (a_tr && !b_tr) return plain_big<true, false>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
+    return plain_big<true, true>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
+}

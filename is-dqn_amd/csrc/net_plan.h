@@ -1,0 +1,224 @@
+// Host-side plan of the Q-network: layer geometry, internal parameter layout and workspace map.
+// Mirrors slimdqn/networks/architectures/dqn.py:47-103 (cnn / fc branches) and the
+// (1+K)*A head view of slimdqn/networks/isdqn.py:34-41.
+#pragma once
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace isdqn {
+
+constexpr int MAX_LAYERS = 12;
+constexpr int LN_MAX_BLOCKS = 256;  // partial-sum slabs of the LayerNorm backward
+
+struct Layer {
+    int kind;  // 0 conv, 1 dense
+    int has_ln, has_relu, is_head;
+    // conv geometry (SAME padding, dqn.py:55-69; kernel/stride fixed by the reference: 8/4, 4/2, 3/1)
+    int hin, win, cin, cin_p, hout, wout, cout, cout_p, ksz, stride, pad, taps, npix;
+    int is_u8;  // first conv: reads uint8 frames through the id table, K order = (plane, ky, kx)
+    // dense
+    int in_f, in_p;  // true / internal input width (in_p: padded to 8; after a conv torso: npix * cout_p)
+    int in_unpadded_ld;  // fc first layer: the caller's obs matrix has ld = in_f
+    int out_f, out_p;    // true / padded output width (conv: cout / cout_p)
+    int K;               // forward contraction length (internal)
+    int in_elems_p, out_elems_p;  // per-image element counts (internal)
+    // parameters (float offsets into the flat buffer); -1 if absent
+    int64_t w_off, b_off, g_off, be_off, w_size;
+    // workspace (float offsets)
+    int64_t act_off, z_off, dz_off, gw_off, part_off;
+    int gw_slabs;   // split-K slabs of the weight gradient
+    int fwd_splits; // dense: split-K factor of the forward GEMM
+    char name[16];
+    char ln_name[16];
+};
+
+struct Plan {
+    int n_layers;
+    Layer L[MAX_LAYERS];
+    int B, N2;
+    int n_heads, n_actions, nha, nha_p;
+    int64_t n_params;
+    // workspace (float offsets unless noted)
+    int64_t q_off, dout_off, da_off, slab_off, qv_off, tg_off, dbh_off, adam_tab_off;
+    int64_t slab_floats, da_floats;
+    int64_t ws_bytes;
+    std::vector<std::pair<std::string, std::pair<int64_t, int64_t>>> regions;  // name -> (byte offset, byte size)
+};
+
+static inline void same_padding(int size, int k, int s, int& out, int& lo) {
+    out = (size + s - 1) / s;
+    int total = (out - 1) * s + k - size;
+    if (total < 0) total = 0;
+    lo = total / 2;
+}
+
+static inline int build_plan(const isdqn_net_config* cfg, Plan& P) {
+    ISDQN_REQUIRE(cfg != nullptr, ISDQN_ERR_ARG, "null config");
+    ISDQN_REQUIRE(cfg->arch == ISDQN_ARCH_CNN || cfg->arch == ISDQN_ARCH_FC, ISDQN_ERR_UNSUPPORTED,
+                  "architecture_type must be cnn or fc (impala is outside the hot-path scope)");
+    ISDQN_REQUIRE(cfg->n_features >= (cfg->arch == ISDQN_ARCH_CNN ? 3 : 0) && cfg->n_features <= ISDQN_MAX_FEATURES,
+                  ISDQN_ERR_ARG, "bad n_features");
+    ISDQN_REQUIRE(cfg->n_actions >= 1 && cfg->n_heads >= 2, ISDQN_ERR_ARG, "need n_actions >= 1 and n_heads >= 2");
+    ISDQN_REQUIRE(cfg->batch_size >= 1 && cfg->batch_size <= 4096, ISDQN_ERR_ARG, "batch_size must be in [1, 4096]");
+    ISDQN_REQUIRE(cfg->precision == ISDQN_PRECISION_BF16X3 || cfg->precision == ISDQN_PRECISION_BF16, ISDQN_ERR_ARG,
+                  "bad precision");
+    P.regions.clear();
+    P.B = cfg->batch_size;
+    P.N2 = 2 * P.B;
+    P.n_heads = cfg->n_heads;
+    P.n_actions = cfg->n_actions;
+    P.nha = cfg->n_heads * cfg->n_actions;
+    P.nha_p = round_up(P.nha, 8);
+    int nl = 0;
+    int n_conv = 0, n_dense = 0, n_ln = 0;
+    int64_t poff = 0;
+    int in_elems_p = 0, in_f = 0, in_p = 0;
+    static const int KS[3] = {8, 4, 3}, ST[3] = {4, 2, 1};
+
+    auto finish_params = [&](Layer& l) {
+        l.w_off = poff;
+        poff += l.w_size;
+        l.b_off = poff;
+        poff += l.out_p;
+        if (l.has_ln) {
+            l.g_off = poff;
+            poff += l.out_p;
+            l.be_off = poff;
+            poff += l.out_p;
+            snprintf(l.ln_name, sizeof(l.ln_name), "LayerNorm_%d", n_ln++);
+        } else {
+            l.g_off = l.be_off = -1;
+            l.ln_name[0] = 0;
+        }
+    };
+
+    if (cfg->arch == ISDQN_ARCH_CNN) {
+        ISDQN_REQUIRE(cfg->obs_h >= 8 && cfg->obs_w >= 8 && cfg->obs_c >= 1 && cfg->obs_c <= 16, ISDQN_ERR_ARG,
+                      "bad observation shape");
+        int h = cfg->obs_h, w = cfg->obs_w, c = cfg->obs_c, c_p = cfg->obs_c;
+        for (int i = 0; i < 3; ++i) {
+            Layer& l = P.L[nl++];
+            memset(&l, 0, sizeof(l));
+            l.kind = 0;
+            l.has_ln = cfg->layer_norm ? 1 : 0;
+            l.has_relu = 1;
+            l.is_u8 = (i == 0);
+            l.hin = h; l.win = w; l.cin = c; l.cin_p = c_p;
+            l.ksz = KS[i]; l.stride = ST[i]; l.taps = KS[i] * KS[i];
+            int pad_w;
+            same_padding(h, l.ksz, l.stride, l.hout, l.pad);
+            same_padding(w, l.ksz, l.stride, l.wout, pad_w);
+            ISDQN_REQUIRE(pad_w == l.pad, ISDQN_ERR_UNSUPPORTED, "non-square padding is not supported");
+            l.cout = cfg->features[i];
+            ISDQN_REQUIRE(l.cout >= 1 && l.cout <= 64, ISDQN_ERR_UNSUPPORTED,
+                          "conv widths above 64 channels are not supported by the fused LayerNorm epilogue");
+            l.cout_p = round_up(l.cout, 8);
+            l.npix = l.hout * l.wout;
+            l.out_f = l.cout; l.out_p = l.cout_p;
+            l.K = l.is_u8 ? l.cin * 64 : l.taps * l.cin_p;
+            l.in_elems_p = l.hin * l.win * l.cin_p;
+            l.out_elems_p = l.npix * l.cout_p;
+            l.w_size = (int64_t)l.cout_p * l.K;
+            snprintf(l.name, sizeof(l.name), "Conv_%d", n_conv++);
+            finish_params(l);
+            h = l.hout; w = l.wout; c = l.cout; c_p = l.cout_p;
+        }
+        in_elems_p = h * w * c_p;
+        in_f = h * w * c;
+        in_p = in_elems_p;
+    } else {
+        ISDQN_REQUIRE(cfg->obs_c >= 1, ISDQN_ERR_ARG, "bad observation dim");
+        in_f = cfg->obs_c;
+        in_p = round_up(in_f, 8);
+        in_elems_p = in_p;
+    }
+    const int first_dense = cfg->arch == ISDQN_ARCH_CNN ? 3 : 0;
+    for (int i = first_dense; i <= cfg->n_features; ++i) {
+        ISDQN_REQUIRE(nl < MAX_LAYERS, ISDQN_ERR_ARG, "too many layers");
+        Layer& l = P.L[nl++];
+        memset(&l, 0, sizeof(l));
+        l.kind = 1;
+        l.is_head = (i == cfg->n_features);
+        l.has_ln = (!l.is_head && cfg->layer_norm) ? 1 : 0;
+        l.has_relu = l.is_head ? 0 : 1;
+        l.in_f = in_f; l.in_p = in_p;
+        l.in_unpadded_ld = (cfg->arch == ISDQN_ARCH_FC && i == 0) ? in_f : 0;
+        l.out_f = l.is_head ? P.nha : cfg->features[i];
+        ISDQN_REQUIRE(l.out_f >= 1 && l.out_f <= 8192, ISDQN_ERR_ARG, "bad dense width");
+        l.out_p = round_up(l.out_f, 8);
+        l.K = l.in_p;
+        l.in_elems_p = in_elems_p;
+        l.out_elems_p = l.out_p;
+        l.w_size = (int64_t)l.out_p * l.in_p;
+        snprintf(l.name, sizeof(l.name), "Dense_%d", n_dense++);
+        finish_params(l);
+        in_f = l.out_f; in_p = l.out_p; in_elems_p = l.out_p;
+    }
+    P.n_layers = nl;
+    P.n_params = poff;
+
+    // ---- workspace ----
+    int64_t off = 0;  // floats
+    auto region = [&](const std::string& name, int64_t floats) {
+        int64_t o = off;
+        floats = (floats + 63) / 64 * 64;  // 256-B granules
+        P.regions.push_back({name, {o * 4, floats * 4}});
+        off += floats;
+        return o;
+    };
+    P.da_floats = 0;
+    P.slab_floats = 0;
+    for (int i = 0; i < nl; ++i) {
+        Layer& l = P.L[i];
+        l.act_off = l.z_off = l.dz_off = l.part_off = -1;
+        if (!l.is_head) {
+            l.act_off = region(std::string("act/") + l.name, (int64_t)P.N2 * l.out_elems_p);
+            l.z_off = region(std::string("z/") + l.name, (int64_t)P.B * l.out_elems_p);
+            l.dz_off = region(std::string("dz/") + l.name, (int64_t)P.B * l.out_elems_p);
+            l.part_off = region(std::string("part/") + l.name, (int64_t)LN_MAX_BLOCKS * 3 * l.out_p);
+        }
+        if (i > 0 && (int64_t)P.B * l.in_elems_p > P.da_floats) P.da_floats = (int64_t)P.B * l.in_elems_p;
+        // weight-gradient slabs: split the contraction (online pixels / batch rows) over workgroups
+        if (l.kind == 0) {
+            int tiles_n = ceil_div(l.K, 64);
+            int ksteps = ceil_div(P.B * l.npix, 32);
+            int s = 256 / tiles_n;
+            if (s < 1) s = 1;
+            if (s > ksteps) s = ksteps;
+            l.gw_slabs = s;
+        } else {
+            int tiles = ceil_div(l.out_p, 128) * ceil_div(l.in_p, 128);
+            int ksteps = ceil_div(P.B, 32);
+            int s = tiles >= 128 ? 1 : 256 / tiles;
+            if (s > ksteps) s = ksteps;
+            if (s < 1) s = 1;
+            l.gw_slabs = s;
+            // forward split-K slabs
+            int ft = ceil_div(P.N2, 128) * ceil_div(l.out_p, 128);
+            int fs = ft >= 128 ? 1 : 256 / ft;
+            int fk = ceil_div(l.K, 32);
+            if (fs > fk) fs = fk;
+            if (fs < 1) fs = 1;
+            l.fwd_splits = fs;
+            int64_t need = (int64_t)fs * P.N2 * l.out_p;
+            if (need > P.slab_floats) P.slab_floats = need;
+        }
+        l.gw_off = region(std::string("gw/") + l.name, (int64_t)l.gw_slabs * l.w_size);
+    }
+    P.q_off = region("q", (int64_t)P.N2 * P.nha_p);
+    P.dout_off = region("dout", (int64_t)P.B * P.nha_p);
+    P.da_off = region("da", P.da_floats);
+    P.slab_off = region("slab", P.slab_floats);
+    P.qv_off = region("q_values", (int64_t)P.B * (P.n_heads - 1));
+    P.tg_off = region("targets", (int64_t)P.B * (P.n_heads - 1));
+    P.dbh_off = region("dbh", P.nha_p);
+    P.adam_tab_off = region("adam_table", 4096);
+    P.ws_bytes = off * 4;
+    return ISDQN_OK;
+}
+
+}  // namespace isdqn

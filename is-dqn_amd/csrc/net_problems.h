@@ -1,0 +1,401 @@
+// Problem definitions (operand loaders + epilogues) that instantiate the MFMA tile engine for
+// every contraction of the iS-DQN gradient step.  See gemm_core.h for the engine contract.
+//
+// Data layouts in HBM (all fp32 unless noted):
+//   frames      uint8 [slot][H*W]                     single frames of the device replay
+//   activations [image][y][x][c padded to 8]          channel-last, like the reference (NHWC)
+//   conv kernel [out][ky][kx][in padded to 8]         (first conv: [out][plane][ky][kx])
+//   dense kernel[out][in]
+// Forward GEMMs put the OUTPUT CHANNELS on the MFMA rows (M) and pixels on the columns (N):
+// a pixel's channels then sit in 4 lanes x (MT*4) registers, so LayerNorm over channels
+// (dqn.py:56-57: nn.LayerNorm() normalises the last axis only) is two wave shuffles.
+#pragma once
+#include "gemm_core.h"
+
+namespace isdqn {
+
+// ---------------------------------------------------------------------------------------------
+// uint8 frame access: image j, plane c -> frame slot through the id table
+// ---------------------------------------------------------------------------------------------
+struct FrameSrc {
+    const uint8_t* frames;
+    int64_t stride;
+    const int* ids;
+    int stack;
+    int paired_B;  // > 0: learn layout ids[b][2*stack] and images [0,B) = states, [B,2B) = next states
+    int H, W;
+    __device__ __forceinline__ int frame_id(int j, int c) const {
+        if (paired_B > 0) {
+            return j < paired_B ? ids[(int64_t)j * 2 * stack + c] : ids[(int64_t)(j - paired_B) * 2 * stack + stack + c];
+        }
+        return ids[(int64_t)j * stack + c];
+    }
+    // 8 horizontally adjacent pixels (ix0 .. ix0+7) of row iy, zero outside the frame; exact in bf16
+    __device__ __forceinline__ void patch8(int j, int c, int iy, int ix0, float (&v)[8]) const {
+        int id = frame_id(j, c);
+        if (id < 0 || iy < 0 || iy >= H) {
+            zero8(v);
+            return;
+        }
+        const uint8_t* row = frames + (int64_t)id * stride + (int64_t)iy * W;
+        if (ix0 >= 0 && ix0 + 8 <= W) {
+            uint2 u;
+            __builtin_memcpy(&u, row + ix0, 8);  // one (unaligned) global_load_dwordx2
+            v[0] = (float)(u.x & 0xff); v[1] = (float)((u.x >> 8) & 0xff);
+            v[2] = (float)((u.x >> 16) & 0xff); v[3] = (float)(u.x >> 24);
+            v[4] = (float)(u.y & 0xff); v[5] = (float)((u.y >> 8) & 0xff);
+            v[6] = (float)((u.y >> 16) & 0xff); v[7] = (float)(u.y >> 24);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int ix = ix0 + i;
+                v[i] = (ix >= 0 && ix < W) ? (float)row[ix] : 0.f;
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Plain GEMM over row-major matrices (dense forward / data-grad / weight-grad, head, self-test)
+//   C[split][m][n] = sum_{k in split} A(m,k) * B(n,k)
+// ---------------------------------------------------------------------------------------------
+template <int BM_, int BN_, int WM_, int WN_, bool ATR, bool BTR, int PASSES_>
+struct PlainGemm {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, PASSES = PASSES_;
+    static constexpr bool A_TR = ATR, B_TR = BTR;
+    MatSrc A, B;       // ROW: outer = rows, inner = K ; TR: outer = K, inner = rows
+    const float* A2;   // optional second part of A (ROW only): rows >= a_split come from A2
+    int a_split;
+    float* C;
+    int ldc, M, N, K;
+    int tiles_m, tiles_n, splits, steps_per_split;
+    int64_t slab_stride;
+    struct Tile { int m0, n0, k0, k1, split; };
+    struct ACtx { int fixed; };
+    struct BCtx { int fixed; };
+    __device__ __forceinline__ bool tile(int bid, Tile& t) const {
+        int tm = bid % tiles_m, rest = bid / tiles_m;
+        int tn = rest % tiles_n;
+        t.split = rest / tiles_n;
+        if (t.split >= splits) return false;
+        t.m0 = tm * BM;
+        t.n0 = tn * BN;
+        t.k0 = t.split * steps_per_split * GEMM_BK;
+        t.k1 = min(K, t.k0 + steps_per_split * GEMM_BK);
+        return true;
+    }
+    __device__ __forceinline__ ACtx a_ctx(const Tile&, int fixed) const { return ACtx{fixed}; }
+    __device__ __forceinline__ BCtx b_ctx(const Tile&, int fixed) const { return BCtx{fixed}; }
+    __device__ __forceinline__ void load_a(const Tile&, const ACtx& c, int var, float (&v)[8]) const {
+        if constexpr (!ATR) {
+            if (A2 != nullptr && c.fixed >= a_split) {
+                MatSrc s = A;
+                s.base = A2;
+                s.outer = A.outer - a_split;
+                s.load(c.fixed - a_split, var, v);
+            } else {
+                MatSrc s = A;
+                if (A2 != nullptr) s.outer = a_split;
+                s.load(c.fixed, var, v);
+            }
+        } else {
+            A.load(var, c.fixed, v);
+        }
+    }
+    __device__ __forceinline__ void load_b(const Tile&, const BCtx& c, int var, float (&v)[8]) const {
+        if constexpr (!BTR) B.load(c.fixed, var, v);
+        else B.load(var, c.fixed, v);
+    }
+    template <int MT, int NT>
+    __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const {
+        float* c = C + (int64_t)t.split * slab_stride;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                int col = n_wave + nt * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row = m_wave + mt * 16 + (lane >> 4) * 4 + r;
+                    if (row < M && col < N) c[(int64_t)row * ldc + col] = acc[mt][nt][r];
+                }
+            }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Convolution geometry shared by the conv problems
+// ---------------------------------------------------------------------------------------------
+struct ConvGeom {
+    int hin, win, cin_p, hout, wout, cout, cout_p, ksz, stride, pad, npix, K;
+    FastDiv d_npix, d_wout, d_cinp, d_ksz, d_coutp;
+};
+
+// Forward convolution + bias + LayerNorm(channels) + ReLU, fused (dqn.py:55-58, 62-65, 69-72).
+//   M = output channels (BM >= cout_p, WM = 1), N = output pixels of all images, K = taps*cin_p.
+template <int BM_, int PASSES_, bool U8>
+struct ConvFwd {
+    static constexpr int BM = BM_, BN = 128, WM = 1, WN = 4, PASSES = PASSES_;
+    static constexpr bool A_TR = false, B_TR = false;
+    ConvGeom g;
+    MatSrc W;            // [cout_p][K]
+    const float* in;     // fp32 NHWC input (if !U8)
+    FrameSrc fs;         // uint8 frames (if U8)
+    const float *bias, *gamma, *beta;  // gamma == nullptr: no LayerNorm
+    float scale;         // 1/255 folded into the first conv (dqn.py:51)
+    float* act;          // [n_pix_total][cout_p]
+    float* z;            // pre-LayerNorm output for the first z_pix pixels (needed by the backward)
+    int n_pix_total, z_pix;
+    struct Tile { int m0, n0, k0, k1; };
+    struct ACtx { int row; };
+    struct BCtx { int j, iy0, ix0, valid; };
+    __device__ __forceinline__ bool tile(int bid, Tile& t) const {
+        t.m0 = 0; t.n0 = bid * BN; t.k0 = 0; t.k1 = g.K;
+        return t.n0 < n_pix_total;
+    }
+    __device__ __forceinline__ ACtx a_ctx(const Tile&, int row) const { return ACtx{row}; }
+    __device__ __forceinline__ void load_a(const Tile&, const ACtx& c, int k, float (&v)[8]) const { W.load(c.row, k, v); }
+    __device__ __forceinline__ BCtx b_ctx(const Tile&, int pix) const {
+        BCtx c;
+        c.valid = pix < n_pix_total;
+        uint32_t j, p, oy, ox;
+        g.d_npix.divmod(c.valid ? pix : 0, j, p);
+        g.d_wout.divmod(p, oy, ox);
+        c.j = (int)j;
+        c.iy0 = (int)oy * g.stride - g.pad;
+        c.ix0 = (int)ox * g.stride - g.pad;
+        return c;
+    }
+    __device__ __forceinline__ void load_b(const Tile&, const BCtx& c, int k, float (&v)[8]) const {
+        if (!c.valid || k >= g.K) { zero8(v); return; }
+        if constexpr (U8) {
+            fs.patch8(c.j, k >> 6, c.iy0 + ((k >> 3) & 7), c.ix0, v);
+        } else {
+            uint32_t tap, ci, ky, kx;
+            g.d_cinp.divmod(k, tap, ci);
+            g.d_ksz.divmod(tap, ky, kx);
+            int iy = c.iy0 + (int)ky, ix = c.ix0 + (int)kx;
+            if (iy < 0 || iy >= g.hin || ix < 0 || ix >= g.win) { zero8(v); return; }
+            load8_aligned(in + (((int64_t)c.j * g.hin + iy) * g.win + ix) * g.cin_p + ci, v);
+        }
+    }
+    template <int MT, int NT>
+    __device__ __forceinline__ void epilogue(const Tile&, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const {
+        const int grp = lane >> 4;
+        float bi[MT][4], ga[MT][4], be[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int ch = m_wave + mt * 16 + grp * 4 + r;
+                bool ok = ch < g.cout;
+                bi[mt][r] = ok ? bias[ch] : 0.f;
+                ga[mt][r] = (ok && gamma) ? gamma[ch] : 1.f;
+                be[mt][r] = (ok && gamma) ? beta[ch] : 0.f;
+            }
+        const float inv_c = 1.0f / (float)g.cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int pix = n_wave + nt * 16 + (lane & 15);
+            float zv[MT][4];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int ch = m_wave + mt * 16 + grp * 4 + r;
+                    float zz = ch < g.cout ? acc[mt][nt][r] * scale + bi[mt][r] : 0.f;
+                    zv[mt][r] = zz;
+                    s1 += zz;
+                    s2 += zz * zz;
+                }
+            float mean = 0.f, rstd = 1.f;
+            if (gamma != nullptr) {  // wave-uniform
+                s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+                mean = s1 * inv_c;
+                float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+                rstd = rsqrtf(var + 1e-6f);
+            }
+            if (pix < n_pix_total) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    int ch0 = m_wave + mt * 16 + grp * 4;
+                    if (ch0 >= g.cout_p) continue;
+                    float4 a, zq;
+                    float* ap = &a.x;
+                    float* zp = &zq.x;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float y = gamma != nullptr ? (zv[mt][r] - mean) * (rstd * ga[mt][r]) + be[mt][r] : zv[mt][r];
+                        ap[r] = (ch0 + r < g.cout) ? fmaxf(y, 0.f) : 0.f;
+                        zp[r] = zv[mt][r];
+                    }
+                    *reinterpret_cast<float4*>(act + (int64_t)pix * g.cout_p + ch0) = a;
+                    if (pix < z_pix) *reinterpret_cast<float4*>(z + (int64_t)pix * g.cout_p + ch0) = zq;
+                }
+            }
+        }
+    }
+};
+
+// Data gradient of a strided SAME convolution, gather form, one stride-parity class per tile:
+//   da[j, iy, ix, ci] = sum_{ky,kx,co} dz[j, (iy+pad-ky)/s, (ix+pad-kx)/s, co] * W[co][ky][kx][ci]
+// Only taps with ky = (iy+pad) mod s (+ multiples of s) hit an output pixel, so input pixels are
+// grouped by (iy mod s, ix mod s): every class is a dense GEMM with K = (ksz/s)^2 * cout_p.
+//   M = input channels (A = weights, TR image: rows of W are output channels = contraction),
+//   N = input pixels of the class, B = im2col(dz) ROW image.
+template <int BM_, int PASSES_>
+struct ConvDgrad {
+    static constexpr int BM = BM_, BN = 128, WM = 1, WN = 4, PASSES = PASSES_;
+    static constexpr bool A_TR = true, B_TR = false;
+    ConvGeom g;
+    const float* W;   // [cout_p][taps][cin_p]
+    const float* dz;  // [n_img][hout][wout][cout_p]
+    float* da;        // [n_img][hin][win][cin_p]
+    int n_img, T, Kc; // T = ksz/stride taps per dim per class, Kc = T*T*cout_p
+    int tile_start[5];   // prefix of tiles per class (stride^2 <= 4 classes)
+    int n_classes;
+    FastDiv cls_d_hw[4], cls_d_w[4];  // per class: divide by Ha*Wb and by Wb
+    struct Tile { int m0, n0, k0, k1, cy, cx, py, px, Ha, Wb, Nc; FastDiv d_hw, d_w; };
+    struct ACtx { int ci0; };
+    struct BCtx { int j, oyb, oxb, valid; };
+    __device__ __forceinline__ bool tile(int bid, Tile& t) const {
+        int cls = 0;
+        while (cls + 1 < n_classes && bid >= tile_start[cls + 1]) ++cls;
+        if (bid >= tile_start[n_classes]) return false;
+        t.cy = cls / g.stride; t.cx = cls % g.stride;
+        t.Ha = (g.hin - t.cy + g.stride - 1) / g.stride;
+        t.Wb = (g.win - t.cx + g.stride - 1) / g.stride;
+        t.Nc = n_img * t.Ha * t.Wb;
+        t.py = (t.cy + g.pad) % g.stride; t.px = (t.cx + g.pad) % g.stride;
+        t.m0 = 0; t.n0 = (bid - tile_start[cls]) * BN; t.k0 = 0; t.k1 = Kc;
+        t.d_hw = cls_d_hw[cls];
+        t.d_w = cls_d_w[cls];
+        return true;
+    }
+    __device__ __forceinline__ ACtx a_ctx(const Tile&, int ci0) const { return ACtx{ci0}; }
+    __device__ __forceinline__ void load_a(const Tile& t, const ACtx& c, int k, float (&v)[8]) const {
+        if (k >= Kc || c.ci0 >= g.cin_p) { zero8(v); return; }
+        uint32_t jt, co;
+        g.d_coutp.divmod(k, jt, co);
+        int jy = (int)jt / T, jx = (int)jt % T;
+        int ky = t.py + g.stride * jy, kx = t.px + g.stride * jx;
+        load8_aligned(W + (int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + c.ci0, v);
+    }
+    __device__ __forceinline__ void decode(const Tile& t, int q, int& j, int& iy, int& ix) const {
+        uint32_t jj, rem, a, b;
+        t.d_hw.divmod(q, jj, rem);
+        t.d_w.divmod(rem, a, b);
+        j = (int)jj; iy = t.cy + g.stride * (int)a; ix = t.cx + g.stride * (int)b;
+    }
+    __device__ __forceinline__ BCtx b_ctx(const Tile& t, int q) const {
+        BCtx c;
+        c.valid = q < t.Nc;
+        int iy, ix;
+        decode(t, c.valid ? q : 0, c.j, iy, ix);
+        c.oyb = (iy + g.pad - t.py) / g.stride;
+        c.oxb = (ix + g.pad - t.px) / g.stride;
+        return c;
+    }
+    __device__ __forceinline__ void load_b(const Tile&, const BCtx& c, int k, float (&v)[8]) const {
+        if (!c.valid || k >= Kc) { zero8(v); return; }
+        uint32_t jt, co;
+        g.d_coutp.divmod(k, jt, co);
+        int jy = (int)jt / T, jx = (int)jt % T;
+        int oy = c.oyb - jy, ox = c.oxb - jx;
+        if (oy < 0 || oy >= g.hout || ox < 0 || ox >= g.wout) { zero8(v); return; }
+        load8_aligned(dz + (((int64_t)c.j * g.hout + oy) * g.wout + ox) * g.cout_p + co, v);
+    }
+    template <int MT, int NT>
+    __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            int q = n_wave + nt * 16 + (lane & 15);
+            if (q >= t.Nc) continue;
+            int j, iy, ix;
+            decode(t, q, j, iy, ix);
+            float* dst = da + (((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                int ch0 = m_wave + mt * 16 + (lane >> 4) * 4;
+                if (ch0 >= g.cin_p) continue;
+                *reinterpret_cast<float4*>(dst + ch0) = float4{acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+            }
+        }
+    }
+};
+
+// Weight gradient of a convolution: dW[co][k'] = sum_pix dz[pix][co] * im2col(in)[pix][k'].
+// The contraction index (pixels) is the slow one of BOTH operands in memory -> both TR images.
+//   M = cout, N = K' = taps*cin_p, K = online pixels, split over workgroups into fp32 slabs.
+template <int PASSES_, bool U8>
+struct ConvWgrad {
+    static constexpr int BM = 64, BN = 64, WM = 2, WN = 2, PASSES = PASSES_;
+    static constexpr bool A_TR = true, B_TR = true;
+    ConvGeom g;
+    MatSrc DZ;        // [n_pix][cout_p]: outer = pixels (K), inner = cout_p
+    const float* in;  // fp32 NHWC input (if !U8)
+    FrameSrc fs;
+    float* slabs;     // [splits][cout_p][K']
+    float scale;      // 1/255 of the first conv (the network input is frames/255, dqn.py:51)
+    int n_pix, tiles_n, splits, steps_per_split;
+    struct Tile { int m0, n0, k0, k1, split; };
+    struct ACtx { int co0; };
+    struct BCtx { int c_or_ci, ky, kx, valid; };
+    __device__ __forceinline__ bool tile(int bid, Tile& t) const {
+        int tn = bid % tiles_n;
+        t.split = bid / tiles_n;
+        if (t.split >= splits) return false;
+        t.m0 = 0; t.n0 = tn * BN;
+        t.k0 = t.split * steps_per_split * GEMM_BK;
+        t.k1 = min(n_pix, t.k0 + steps_per_split * GEMM_BK);
+        return true;
+    }
+    __device__ __forceinline__ ACtx a_ctx(const Tile&, int co0) const { return ACtx{co0}; }
+    __device__ __forceinline__ void load_a(const Tile&, const ACtx& c, int pix, float (&v)[8]) const { DZ.load(pix, c.co0, v); }
+    __device__ __forceinline__ BCtx b_ctx(const Tile&, int kp) const {
+        BCtx c;
+        c.valid = kp < g.K;
+        if constexpr (U8) {
+            c.c_or_ci = kp >> 6; c.ky = (kp >> 3) & 7; c.kx = 0;
+        } else {
+            uint32_t tap, ci, ky, kx;
+            g.d_cinp.divmod(c.valid ? kp : 0, tap, ci);
+            g.d_ksz.divmod(tap, ky, kx);
+            c.c_or_ci = (int)ci; c.ky = (int)ky; c.kx = (int)kx;
+        }
+        return c;
+    }
+    __device__ __forceinline__ void load_b(const Tile&, const BCtx& c, int pix, float (&v)[8]) const {
+        if (!c.valid || pix >= n_pix) { zero8(v); return; }
+        uint32_t j, p, oy, ox;
+        g.d_npix.divmod(pix, j, p);
+        g.d_wout.divmod(p, oy, ox);
+        int iy = (int)oy * g.stride - g.pad + c.ky;
+        int ix = (int)ox * g.stride - g.pad + c.kx;
+        if constexpr (U8) {
+            fs.patch8((int)j, c.c_or_ci, iy, ix, v);
+        } else {
+            if (iy < 0 || iy >= g.hin || ix < 0 || ix >= g.win) { zero8(v); return; }
+            load8_aligned(in + (((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + c.c_or_ci, v);
+        }
+    }
+    template <int MT, int NT>
+    __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const {
+        float* c = slabs + (int64_t)t.split * g.cout_p * g.K;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                int col = n_wave + nt * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row = m_wave + mt * 16 + (lane >> 4) * 4 + r;
+                    if (row < g.cout_p && col < g.K) c[(int64_t)row * g.K + col] = acc[mt][nt][r] * scale;
+                }
+            }
+    }
+};
+
+}  // namespace isdqn

@@ -1,0 +1,282 @@
+"""Host-side driver of the HIP Q-network: configuration, parameter import/export between the
+reference's Flax pytree layout and the library's internal layout, workspace ownership, and thin
+wrappers over the C-ABI entry points.  Pure plumbing: no arithmetic of the hot path lives here.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Sequence
+
+import numpy as np
+import torch
+
+from slimdqn import _hip
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class QNetEngine:
+    """One Q-network (slimdqn/networks/architectures/dqn.py DQNNet + isdqn.py head view) on one GPU."""
+
+    def __init__(
+        self,
+        observation_dim: Sequence[int],
+        n_actions: int,
+        n_heads: int,
+        features: Sequence[int],
+        architecture_type: str,
+        layer_norm: bool,
+        batch_size: int,
+        gamma_n: float = 0.99,
+        learning_rate: float = 1e-3,
+        adam_eps: float = 1e-8,
+        precision: str = "bf16x3",
+        device: str = "cuda:0",
+    ):
+        _hip.require_gpu()
+        self.lib = _hip.lib()
+        self.device = torch.device(device)
+        cfg = _hip.NetConfig()
+        if architecture_type == "cnn":
+            cfg.arch = _hip.ARCH_CNN
+            cfg.obs_h, cfg.obs_w, cfg.obs_c = (int(d) for d in observation_dim)
+        elif architecture_type == "fc":
+            cfg.arch = _hip.ARCH_FC
+            cfg.obs_h = cfg.obs_w = 1
+            cfg.obs_c = int(np.prod(observation_dim))
+        else:
+            raise NotImplementedError(f"architecture_type={architecture_type!r}: only 'cnn' and 'fc' are on the hot path")
+        feats = [int(f) for f in features]
+        if len(feats) > _hip.MAX_FEATURES:
+            raise ValueError("too many features")
+        cfg.n_features = len(feats)
+        for i, f in enumerate(feats):
+            cfg.features[i] = f
+        cfg.n_actions = int(n_actions)
+        cfg.n_heads = int(n_heads)
+        cfg.layer_norm = 1 if layer_norm else 0
+        cfg.batch_size = int(batch_size)
+        cfg.precision = {"bf16x3": _hip.PRECISION_BF16X3, "bf16": _hip.PRECISION_BF16}[precision]
+        cfg.gamma_n = float(gamma_n)
+        cfg.learning_rate = float(learning_rate)
+        cfg.adam_b1, cfg.adam_b2 = 0.9, 0.999
+        cfg.adam_eps = float(adam_eps)
+        self.cfg = cfg
+        self.features = feats
+        self.architecture_type = architecture_type
+        self.observation_dim = tuple(int(d) for d in observation_dim)
+        self.n_actions, self.n_heads = int(n_actions), int(n_heads)
+        self.batch_size = int(batch_size)
+        self.precision = precision
+
+        n = ctypes.c_int64()
+        cnt = ctypes.c_int32()
+        _hip.check(self.lib.isdqn_net_param_layout(ctypes.byref(cfg), ctypes.byref(n), None, 0, ctypes.byref(cnt)))
+        infos = (_hip.TensorInfo * cnt.value)()
+        _hip.check(self.lib.isdqn_net_param_layout(ctypes.byref(cfg), ctypes.byref(n), infos, cnt.value, ctypes.byref(cnt)))
+        self.n_param_floats = int(n.value)
+        self.infos = list(infos)
+        wb = ctypes.c_int64()
+        _hip.check(self.lib.isdqn_net_workspace_bytes(ctypes.byref(cfg), ctypes.byref(wb)))
+        self.workspace_bytes = int(wb.value)
+        with torch.cuda.device(self.device):
+            # zero-initialised once: padded rows/columns of gradient slabs are never written and must read as 0
+            self.workspace = torch.zeros(self.workspace_bytes // 4, dtype=torch.float32, device=self.device)
+            self.params = torch.zeros(self.n_param_floats, dtype=torch.float32, device=self.device)
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
+            self.adam_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            K = self.n_heads - 1
+            self.losses = torch.zeros(K, dtype=torch.float32, device=self.device)
+            self.q_values = torch.zeros(batch_size, K, dtype=torch.float32, device=self.device)
+            self.targets = torch.zeros(batch_size, K, dtype=torch.float32, device=self.device)
+            self.priorities = torch.zeros(batch_size, dtype=torch.float64, device=self.device)
+            self.action_out = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    # ------------------------------------------------------------------ parameter layout
+    def _first_dense_after_conv(self, info) -> bool:
+        return self.architecture_type == "cnn" and info.kind == 1 and info.layer == 3
+
+    def _to_internal(self, info, arr: np.ndarray) -> np.ndarray:
+        arr = np.asarray(arr, dtype=np.float32)
+        d = list(info.dims)
+        if info.kind == 0:
+            k1, k2, cin, cout = arr.shape
+            if self.architecture_type == "cnn" and info.layer == 0:
+                out = np.zeros((d[0], cin, k1 * k2), np.float32)  # [out][plane][ky*8+kx]
+                out[:cout] = arr.transpose(3, 2, 0, 1).reshape(cout, cin, k1 * k2)
+            else:
+                out = np.zeros((d[0], d[1], d[2]), np.float32)  # [out][tap][in_p]
+                out[:cout, :, :cin] = arr.transpose(3, 0, 1, 2).reshape(cout, k1 * k2, cin)
+            return out.reshape(-1)
+        if info.kind == 1:
+            in_f, out_f = arr.shape
+            out = np.zeros((d[0], d[1]), np.float32)  # [out_p][in_p]
+            if self._first_dense_after_conv(info):
+                c = self.features[2]
+                c_p = _round_up(c, 8)
+                npix = in_f // c
+                tmp = np.zeros((out_f, npix, c_p), np.float32)
+                tmp[:, :, :c] = arr.T.reshape(out_f, npix, c)
+                out[:out_f] = tmp.reshape(out_f, npix * c_p)
+            else:
+                out[:out_f, :in_f] = arr.T
+            return out.reshape(-1)
+        out = np.zeros(d[0], np.float32)
+        out[: arr.shape[0]] = arr
+        return out
+
+    def _from_internal(self, info, flat: np.ndarray) -> np.ndarray:
+        d = list(info.dims)
+        shape = tuple(info.flax_shape[: info.ndim])
+        if info.kind == 0:
+            k1, k2, cin, cout = shape
+            if self.architecture_type == "cnn" and info.layer == 0:
+                w = flat.reshape(d[0], cin, k1, k2)[:cout]
+                return np.ascontiguousarray(w.transpose(2, 3, 1, 0))
+            w = flat.reshape(d[0], k1, k2, d[2])[:cout, :, :, :cin]
+            return np.ascontiguousarray(w.transpose(1, 2, 3, 0))
+        if info.kind == 1:
+            in_f, out_f = shape
+            w = flat.reshape(d[0], d[1])[:out_f]
+            if self._first_dense_after_conv(info):
+                c = self.features[2]
+                c_p = _round_up(c, 8)
+                npix = in_f // c
+                w = w.reshape(out_f, npix, c_p)[:, :, :c].reshape(out_f, in_f)
+            else:
+                w = w[:, :in_f]
+            return np.ascontiguousarray(w.T)
+        return flat[: shape[0]].copy()
+
+    def import_flax(self, params: Dict[str, Dict[str, np.ndarray]], target: torch.Tensor | None = None) -> None:
+        """Load a reference-layout pytree ({"Conv_0": {"kernel": HWIO, "bias"}, "LayerNorm_0": ...})."""
+        flat = np.zeros(self.n_param_floats, np.float32)
+        for info in self.infos:
+            mod, leaf = info.name.decode().split("/")
+            v = self._to_internal(info, params[mod][leaf])
+            assert v.size == info.size, (info.name, v.size, info.size)
+            flat[info.offset : info.offset + info.size] = v
+        (self.params if target is None else target).copy_(torch.from_numpy(flat))
+
+    def export_flax(self, source: torch.Tensor | None = None) -> Dict[str, Dict[str, np.ndarray]]:
+        flat = (self.params if source is None else source).detach().cpu().numpy()
+        out: Dict[str, Dict[str, np.ndarray]] = {}
+        for info in self.infos:
+            mod, leaf = info.name.decode().split("/")
+            out.setdefault(mod, {})[leaf] = self._from_internal(info, flat[info.offset : info.offset + info.size])
+        return out
+
+    def init_params(self, seed: int) -> None:
+        """Flax defaults (dqn.py:49, 90): xavier_uniform for cnn, lecun_normal for fc; biases 0, LN scale 1.
+        Draws come from numpy PCG64 (JAX threefry streams are not reproducible offline)."""
+        rng = np.random.default_rng(seed)
+        params: Dict[str, Dict[str, np.ndarray]] = {}
+        for info in self.infos:
+            mod, leaf = info.name.decode().split("/")
+            shape = tuple(info.flax_shape[: info.ndim])
+            if info.kind in (0, 1):
+                if info.kind == 0:
+                    rf = shape[0] * shape[1]
+                    fan_in, fan_out = rf * shape[2], rf * shape[3]
+                else:
+                    fan_in, fan_out = shape
+                if self.architecture_type == "cnn":
+                    lim = math.sqrt(6.0 / (fan_in + fan_out))
+                    w = rng.uniform(-lim, lim, size=shape)
+                else:
+                    std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+                    w = np.empty(int(np.prod(shape)))
+                    filled = 0
+                    while filled < w.size:
+                        draw = rng.standard_normal(w.size - filled)
+                        draw = draw[np.abs(draw) <= 2.0]
+                        w[filled : filled + draw.size] = draw
+                        filled += draw.size
+                    w = w.reshape(shape) * std
+                params.setdefault(mod, {})[leaf] = w.astype(np.float32)
+            elif info.kind == 3:
+                params.setdefault(mod, {})[leaf] = np.ones(shape, np.float32)
+            else:
+                params.setdefault(mod, {})[leaf] = np.zeros(shape, np.float32)
+        self.import_flax(params)
+
+    # ------------------------------------------------------------------ workspace regions (tests / debugging)
+    def region(self, name: str) -> torch.Tensor:
+        off, size = ctypes.c_int64(), ctypes.c_int64()
+        _hip.check(self.lib.isdqn_net_workspace_region(ctypes.byref(self.cfg), name.encode(), ctypes.byref(off), ctypes.byref(size)))
+        return self.workspace[off.value // 4 : (off.value + size.value) // 4]
+
+    # ------------------------------------------------------------------ C-ABI calls
+    def make_batch(self, *, frames=None, frame_stride=0, frame_ids=None, state=None, next_state=None, action=None, reward=None, terminal=None) -> _hip.Batch:
+        b = _hip.Batch()
+        b.B = self.batch_size
+        b.frames = _hip.ptr(frames)
+        b.frame_stride = int(frame_stride)
+        b.frame_ids = _hip.ptr(frame_ids)
+        b.state = _hip.ptr(state)
+        b.next_state = _hip.ptr(next_state)
+        b.action = _hip.ptr(action)
+        b.reward = _hip.ptr(reward)
+        b.terminal = _hip.ptr(terminal)
+        # keep the tensors alive for the duration of the asynchronous call
+        b._keep = (frames, frame_ids, state, next_state, action, reward, terminal)
+        return b
+
+    def forward(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, n_rows: int, params=None) -> torch.Tensor:
+        q = torch.empty(n_rows, self.n_heads * self.n_actions, dtype=torch.float32, device=self.device)
+        p = self.params if params is None else params
+        _hip.check(
+            self.lib.isdqn_net_forward(
+                ctypes.byref(self.cfg), _hip.ptr(p), _hip.ptr(frames), int(frame_stride), _hip.ptr(frame_ids),
+                _hip.ptr(obs), int(n_rows), _hip.ptr(q), _hip.ptr(self.workspace), _hip.stream_ptr(),
+            ),
+            "isdqn_net_forward",
+        )
+        return q
+
+    def learn_on_batch(self, batch: _hip.Batch, grad_out: torch.Tensor | None = None) -> torch.Tensor:
+        """One gradient step in place; returns the device tensor of per-head losses (no sync)."""
+        args = [
+            ctypes.byref(self.cfg), _hip.ptr(self.params), _hip.ptr(self.adam_m), _hip.ptr(self.adam_v),
+            _hip.ptr(self.adam_count), ctypes.byref(batch), _hip.ptr(self.losses), _hip.ptr(self.q_values),
+            _hip.ptr(self.targets), _hip.ptr(self.priorities), _hip.ptr(self.workspace), _hip.stream_ptr(),
+        ]
+        if grad_out is None:
+            rc = self.lib.isdqn_net_learn_on_batch(*args)
+        else:
+            rc = self.lib.isdqn_net_learn_on_batch_debug(*args, _hip.ptr(grad_out))
+        _hip.check(rc, "isdqn_net_learn_on_batch")
+        return self.losses
+
+    def loss_on_batch(self, batch: _hip.Batch, params=None) -> torch.Tensor:
+        p = self.params if params is None else params
+        _hip.check(
+            self.lib.isdqn_net_loss_on_batch(
+                ctypes.byref(self.cfg), _hip.ptr(p), ctypes.byref(batch), _hip.ptr(self.losses),
+                _hip.ptr(self.q_values), _hip.ptr(self.targets), _hip.ptr(self.workspace), _hip.stream_ptr(),
+            ),
+            "isdqn_net_loss_on_batch",
+        )
+        return self.losses
+
+    def shift_params(self, params=None) -> None:
+        p = self.params if params is None else params
+        _hip.check(self.lib.isdqn_net_shift_params(ctypes.byref(self.cfg), _hip.ptr(p), _hip.stream_ptr()))
+
+    def best_action(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, idx_network: int, params=None) -> torch.Tensor:
+        p = self.params if params is None else params
+        _hip.check(
+            self.lib.isdqn_net_best_action(
+                ctypes.byref(self.cfg), _hip.ptr(p), _hip.ptr(frames), int(frame_stride), _hip.ptr(frame_ids),
+                _hip.ptr(obs), int(idx_network), _hip.ptr(self.action_out), _hip.ptr(self.workspace), _hip.stream_ptr(),
+            ),
+            "isdqn_net_best_action",
+        )
+        return self.action_out
+
+    def internal_to_flax_grads(self, grad_flat: torch.Tensor) -> Dict[str, Dict[str, np.ndarray]]:
+        return self.export_flax(grad_flat)

@@ -1,0 +1,183 @@
+"""ctypes binding of libisdqn_hip.so (C ABI: include/isdqn_hip.h).
+
+The product path has no CPU fallback: if the library is missing this module raises at first
+use.  Device memory and streams come from PyTorch-ROCm (plumbing only); every hot-path
+computation goes through the entry points bound here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libisdqn_hip.so")
+
+OK = 0
+ERR_CAPACITY, ERR_NEGATIVE, ERR_SHAPE, ERR_EMPTY, ERR_RANGE, ERR_UNSUPPORTED, ERR_HIP, ERR_ARG = range(-1, -9, -1)
+STATUS_NEGATIVE_VALUE, STATUS_TARGET_RANGE, STATUS_EMPTY_TREE = 1, 2, 4
+TREE_MAX_BATCH = 4096
+ARCH_CNN, ARCH_FC = 0, 1
+PRECISION_BF16X3, PRECISION_BF16 = 0, 1
+MAX_FEATURES = 8
+
+
+class NetConfig(ctypes.Structure):
+    _fields_ = [
+        ("arch", c_int32),
+        ("obs_h", c_int32),
+        ("obs_w", c_int32),
+        ("obs_c", c_int32),
+        ("n_features", c_int32),
+        ("features", c_int32 * MAX_FEATURES),
+        ("n_actions", c_int32),
+        ("n_heads", c_int32),
+        ("layer_norm", c_int32),
+        ("batch_size", c_int32),
+        ("precision", c_int32),
+        ("gamma_n", c_float),
+        ("learning_rate", c_float),
+        ("adam_b1", c_float),
+        ("adam_b2", c_float),
+        ("adam_eps", c_float),
+    ]
+
+
+class TensorInfo(ctypes.Structure):
+    _fields_ = [
+        ("name", c_char * 48),
+        ("offset", c_int64),
+        ("size", c_int64),
+        ("kind", c_int32),
+        ("layer", c_int32),
+        ("ndim", c_int32),
+        ("flax_shape", c_int32 * 4),
+        ("dims", c_int32 * 4),
+    ]
+
+
+class Batch(ctypes.Structure):
+    _fields_ = [
+        ("B", c_int32),
+        ("frames", c_void_p),
+        ("frame_stride", c_int64),
+        ("frame_ids", c_void_p),
+        ("state", c_void_p),
+        ("next_state", c_void_p),
+        ("action", c_void_p),
+        ("reward", c_void_p),
+        ("terminal", c_void_p),
+    ]
+
+
+_SIGNATURES = {
+    "isdqn_version": (c_char_p, []),
+    "isdqn_last_error": (c_char_p, []),
+    "isdqn_tree_layout": (c_int32, [c_int64, POINTER(c_int32), POINTER(c_int64), POINTER(c_int64)]),
+    "isdqn_tree_set": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "isdqn_tree_swap_remove": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "isdqn_tree_query": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "isdqn_replay_gather_rows": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "isdqn_replay_materialize": (
+        c_int32,
+        [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p],
+    ),
+    "isdqn_replay_deinterleave": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
+    ),
+    "isdqn_net_param_layout": (
+        c_int32,
+        [POINTER(NetConfig), POINTER(c_int64), POINTER(TensorInfo), c_int32, POINTER(c_int32)],
+    ),
+    "isdqn_net_workspace_bytes": (c_int32, [POINTER(NetConfig), POINTER(c_int64)]),
+    "isdqn_net_workspace_region": (c_int32, [POINTER(NetConfig), c_char_p, POINTER(c_int64), POINTER(c_int64)]),
+    "isdqn_net_forward": (
+        c_int32,
+        [POINTER(NetConfig), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p],
+    ),
+    "isdqn_net_learn_on_batch": (
+        c_int32,
+        [POINTER(NetConfig), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "isdqn_net_learn_on_batch_debug": (
+        c_int32,
+        [POINTER(NetConfig), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "isdqn_net_loss_on_batch": (
+        c_int32,
+        [POINTER(NetConfig), c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "isdqn_net_shift_params": (c_int32, [POINTER(NetConfig), c_void_p, c_void_p]),
+    "isdqn_net_best_action": (
+        c_int32,
+        [POINTER(NetConfig), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p],
+    ),
+    "isdqn_selftest_gemm": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    ),
+}
+
+# entry points declared by include/isdqn_hip.h (the debug hook is exported but not part of the header)
+PUBLIC_SYMBOLS = [s for s in _SIGNATURES if s != "isdqn_net_learn_on_batch_debug"]
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded C-ABI library; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python is-dqn_amd/build.py). "
+                "There is no CPU fallback for the iS-DQN hot path."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    return lib().isdqn_last_error().decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map C-ABI status codes onto the reference's exception types (error conventions)."""
+    if rc == OK:
+        return
+    msg = f"{what}: {last_error()}" if what else last_error()
+    if rc in (ERR_CAPACITY, ERR_NEGATIVE, ERR_SHAPE, ERR_EMPTY):
+        raise AssertionError(msg)
+    if rc == ERR_RANGE:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(f"isdqn_hip error {rc}: {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("the iS-DQN HIP path needs a ROCm GPU (torch.cuda.is_available() is False)")
+    lib()

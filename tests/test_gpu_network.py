@@ -1,0 +1,142 @@
+"""GPU parity of the Q-network path against the CPU oracle (fp32/fp64 torch restatement of the
+reference, PARITY UNPINNED for Flax/Optax numerics -- see oracle/network.py), through the C ABI.
+
+Tolerances: BASELINE.md section 4 / north_star: Bellman targets and per-head losses within 1e-3
+of the fp32 restatement for the default (split-bf16) precision.  The single-pass bf16 mode is
+checked against a correspondingly looser bound (bf16 has 8 significant bits)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_helpers import device_batch, make_frame_batch, make_pair
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"bf16x3": dict(q=1e-3, loss=1e-3, grad=3e-3, param=2e-5), "bf16": dict(q=8e-2, loss=5e-2, grad=2.5e-1, param=1e-3)}
+
+CONFIGS = [
+    # feats, K, A, B, layer_norm
+    pytest.param(((7, 9, 11, 13), 3, 5, 6, True), id="tiny-ln"),
+    pytest.param(((16, 20, 5, 24), 2, 3, 5, False), id="tiny-noln"),
+    pytest.param(((32, 64, 64, 512), 9, 9, 8, True), id="headline-arch-B8"),
+]
+
+
+def _flat_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_forward_loss_grad_adam(cfg, precision):
+    feats, K, A, B, ln = cfg
+    tol = TOL[precision]
+    oracle, eng, params = make_pair(feats, K, A, B, layer_norm=ln, precision=precision, seed=3)
+    frames, ids, action, reward, terminal, ref = make_frame_batch(B, A, seed=11)
+    batch = device_batch(eng, frames, ids, action, reward, terminal)
+
+    # ---- forward over concat(state, next_state) ----
+    all_q = oracle.apply(oracle.params, torch.cat((torch.tensor(ref.state), torch.tensor(ref.next_state)))).detach().numpy()
+    flat_ids = np.concatenate([ids[:, :4], ids[:, 4:]], 0).copy()
+    q = eng.forward(frames=batch._keep[0], frame_stride=frames.shape[1], frame_ids=torch.from_numpy(flat_ids).cuda(), n_rows=2 * B)
+    q = q.cpu().numpy().reshape(2 * B, 1 + K, A)
+    assert np.abs(q - all_q).max() < tol["q"], f"forward max err {np.abs(q - all_q).max()}"
+
+    # ---- loss / targets (isdqn.py:92-109) ----
+    o_q, o_t, o_td = oracle.loss_terms(oracle.params, ref)
+    o_loss = o_td.mean(0).detach().numpy()
+    losses = eng.loss_on_batch(batch).cpu().numpy()
+    assert np.abs(eng.targets.cpu().numpy() - o_t.detach().numpy()).max() < tol["q"]
+    assert np.abs(eng.q_values.cpu().numpy() - o_q.detach().numpy()).max() < tol["q"]
+    assert np.abs(losses - o_loss).max() < tol["loss"] * max(1.0, np.abs(o_loss).max())
+
+    # ---- gradient step: gradients (debug hook), Adam, three steps ----
+    grad = torch.zeros_like(eng.params)
+    p, st = oracle.params, oracle.optimizer_state
+    for step in range(3):
+        o_grads, _ = oracle.grads(p, ref)
+        p, st, o_losses = oracle.learn_on_batch(p, st, ref)
+        losses = eng.learn_on_batch(batch, grad_out=grad).cpu().numpy()
+        assert np.abs(losses - o_losses).max() < tol["loss"] * max(1.0, np.abs(o_losses).max()), f"step {step}"
+        if step == 0:
+            g = eng.internal_to_flax_grads(grad)
+            for mod in o_grads:
+                for leaf in o_grads[mod]:
+                    e = _flat_err(g[mod][leaf], o_grads[mod][leaf].numpy())
+                    assert e < tol["grad"], f"grad {mod}/{leaf}: rel err {e}"
+            pri = eng.priorities.cpu().numpy()
+            exp = np.sqrt(o_td.detach().numpy().mean(1) + 1e-10)
+            assert np.abs(pri - exp).max() < 10 * tol["q"] * max(1.0, exp.max())
+    got = eng.export_flax()
+    for mod in p:
+        for leaf in p[mod]:
+            d = np.abs(got[mod][leaf] - p[mod][leaf].numpy()).max()
+            # Adam normalises the step: an element whose gradient is ~0 can flip sign of its update, so the
+            # bound is a few learning rates, tightened by the gradient accuracy
+            assert d < 3 * 1e-3 * 3 * max(tol["grad"] * 50, 0.02) + tol["param"], f"param {mod}/{leaf}: {d}"
+    assert int(eng.adam_count.item()) == 3
+
+
+def test_shift_and_best_action():
+    feats, K, A, B = (7, 9, 11, 13), 4, 6, 4
+    oracle, eng, params = make_pair(feats, K, A, B, seed=5)
+    frames, ids, action, reward, terminal, ref = make_frame_batch(B, A, seed=2)
+    fr = torch.from_numpy(frames).cuda()
+    one = torch.from_numpy(ids[:1, :4].copy()).cuda()
+    q_before = eng.forward(frames=fr, frame_stride=frames.shape[1], frame_ids=one, n_rows=1).cpu().numpy().reshape(1 + K, A)
+    for idx in range(K):
+        a = int(eng.best_action(frames=fr, frame_stride=frames.shape[1], frame_ids=one, idx_network=idx).item())
+        assert a == int(np.argmax(q_before[1 + idx]))
+        assert a == oracle.best_action(oracle.params, ref.state[0], idx)
+    eng.shift_params()
+    q_after = eng.forward(frames=fr, frame_stride=frames.shape[1], frame_ids=one, n_rows=1).cpu().numpy().reshape(1 + K, A)
+    # test_isdqn.py:99-116: the target heads equal the former online heads exactly; last head unchanged
+    assert np.linalg.norm(q_after[:-1] - q_before[1:]) == 0
+    np.testing.assert_array_equal(q_after[-1], q_before[-1])
+    shifted = oracle.shift_params(oracle.params)
+    got = eng.export_flax()
+    np.testing.assert_array_equal(got["Dense_1"]["kernel"], shifted["Dense_1"]["kernel"].numpy())
+    np.testing.assert_array_equal(got["Dense_1"]["bias"], shifted["Dense_1"]["bias"].numpy())
+
+
+def test_param_layout_round_trip():
+    feats, K, A, B = (7, 9, 11, 13), 2, 3, 2
+    oracle, eng, params = make_pair(feats, K, A, B, seed=1)
+    got = eng.export_flax()
+    for mod in params:
+        for leaf in params[mod]:
+            np.testing.assert_array_equal(got[mod][leaf], params[mod][leaf])
+
+
+@pytest.mark.parametrize("precision", ["bf16x3"])
+def test_fc_architecture_lunar_lander_shape(precision):
+    """BASELINE config 1 shape: fc [100,100], K=1, batch 32, 8-dim observations, 4 actions."""
+    from slimdqn._engine import QNetEngine
+    from oracle.isdqn import iSDQN as OracleAgent
+    from oracle.replay_buffer import ReplayElement
+    from tests.gpu_helpers import perturbed_params
+
+    feats, K, A, B, obs = (100, 100), 1, 4, 32, (8,)
+    params = perturbed_params(0, obs, feats, "fc", (1 + K) * A, True)
+    oracle = OracleAgent(0, obs, A, K, list(feats), True, False, "fc", 3e-4, 0.99, 1, 1, 1, adam_eps=1e-8, params=params)
+    eng = QNetEngine(obs, A, 1 + K, feats, "fc", True, B, gamma_n=0.99, learning_rate=3e-4, adam_eps=1e-8, precision=precision)
+    eng.import_flax(params)
+    rng = np.random.default_rng(0)
+    state = rng.normal(size=(B, 8)).astype(np.float32)
+    nxt = rng.normal(size=(B, 8)).astype(np.float32)
+    action = rng.integers(0, A, B).astype(np.int32)
+    reward = rng.normal(size=B).astype(np.float32)
+    term = (rng.random(B) < 0.2).astype(np.uint8)
+    ref = ReplayElement(state=state, action=action.astype(np.int64), reward=reward.astype(np.float64), next_state=nxt, is_terminal=term.astype(np.int64))
+    d = lambda a: torch.from_numpy(a).cuda()
+    batch = eng.make_batch(state=d(state), next_state=d(nxt), action=d(action), reward=d(reward), terminal=d(term))
+    p, st = oracle.params, oracle.optimizer_state
+    for step in range(2):
+        p, st, o_losses = oracle.learn_on_batch(p, st, ref)
+        losses = eng.learn_on_batch(batch).cpu().numpy()
+        assert np.abs(losses - o_losses).max() < 1e-3 * max(1.0, np.abs(o_losses).max())
+    got = eng.export_flax()
+    for mod in p:
+        for leaf in p[mod]:
+            assert np.abs(got[mod][leaf] - p[mod][leaf].numpy()).max() < 3e-4, (mod, leaf)
