@@ -1,0 +1,237 @@
+"""bench.py -- gradient-steps/sec of the iS-DQN replay-sample -> Bellman-update step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5] [--precision bf16x3|bf16]
+
+One "step" = one pass of the hot path over one batch: draw the batch from the device-resident replay
+(uniform PCG64 draw, or float64 sum-tree inverse-CDF query for c3), gather the element rows, run
+iSDQN.learn_on_batch (forward on 2B frame stacks read through the frame-id table, iterated Bellman
+targets over the K heads, squared TD loss, backward, Adam) and, for c3, write sqrt(mean_k td) back into the
+sum tree.  All inputs are resident in HBM when the timed region starts.
+
+Workloads (BASELINE.json configs):
+  c2 (default, configs[1]): Asterix-shaped A=9, K=9, B=256, cnn 32/64/64/512 + LayerNorm, uniform replay, n=1
+  c3 (configs[2]):          same + prioritized replay (sum tree) + n=3 + priority writeback
+  c5 (configs[4]):          Breakout-shaped A=4, K=32, B=1024
+
+N > 1: one process per GPU (torchrun), independent replicas (own seed, own replay, own parameters) --
+the path shards embarrassingly, no data-path collective; RCCL carries only the timing
+reduction.  value = N * K / max-over-ranks(time).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "is-dqn_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    "c2": dict(n_actions=9, K=9, B=256, prioritized=False, n=1, desc="Asterix-shaped iS-DQN K=9 A=9 B=256 cnn32/64/64/512+LN, uniform device replay, n=1"),
+    "c3": dict(n_actions=9, K=9, B=256, prioritized=True, n=3, desc="Asterix-shaped iS-DQN K=9 A=9 B=256 cnn32/64/64/512+LN, prioritized (sum-tree) device replay + writeback, n=3"),
+    "c5": dict(n_actions=4, K=32, B=1024, prioritized=False, n=1, desc="Breakout-shaped iS-DQN K=32 A=4 B=1024 cnn32/64/64/512+LN, uniform device replay, n=1"),
+}
+FEATURES = (32, 64, 64, 512)
+
+
+def algorithmic_bytes_per_step(B, K, A, prioritized):
+    """uint8 frames of state+next_state read once, pre-LN activations of the B online samples
+    saved and re-read once in bf16, 28 bytes per parameter (fp32 weights read in fwd and bwd, Adam reads m,v and
+    writes p,m,v), plus the sum-tree traffic for c3."""
+    P = 4_044_768 + (512 + 1) * (1 + K) * A
+    frames = 2 * B * 28_224
+    acts = B * 30_112 * 2 * 2
+    tree = B * 21 * 24 if prioritized else 0
+    return frames + acts + 28 * P + tree
+
+
+def algorithmic_flops_per_step(B, K, A):
+    mac = 16_003_072 + 512 * (1 + K) * A
+    mac_conv0 = 441 * 256 * 32
+    return 2 * mac * 2 * B + 2 * (2 * mac - mac_conv0) * B
+
+
+class Replica:
+    """One independent (seed) replica of the training state on one GPU."""
+
+    def __init__(self, workload, capacity, precision, seed, device):
+        import torch
+        from slimdqn._engine import QNetEngine
+        from slimdqn.sample_collection.replay_buffer import ReplayBuffer
+        from slimdqn.sample_collection.samplers import PrioritizedSamplingDistribution, UniformSamplingDistribution
+
+        w = WORKLOADS[workload]
+        self.w = w
+        self.device = device
+        if w["prioritized"]:
+            sampler = PrioritizedSamplingDistribution(seed, capacity, device=device)
+        else:
+            sampler = UniformSamplingDistribution(seed, device=device)
+        self.rb = ReplayBuffer(sampler, w["B"], capacity, stack_size=4, update_horizon=w["n"], gamma=0.99, device=device)
+        import numpy as np
+
+        pri = np.random.default_rng(seed).uniform(0.1, 2.0, capacity) if w["prioritized"] else None
+        self.rb.prefill_synthetic(capacity, (84, 84), w["n_actions"], seed=seed, p_terminal=0.005, priorities=pri)
+        self.eng = QNetEngine((84, 84, 4), w["n_actions"], 1 + w["K"], FEATURES, "cnn", True, w["B"],
+                              gamma_n=0.99 ** w["n"], learning_rate=6.25e-5, adam_eps=1.5e-4, precision=precision,
+                              device=device)
+        self.eng.init_params(seed)
+        torch.cuda.synchronize()
+
+    def step(self):
+        batch = self.rb.sample()
+        cb = self.eng.make_batch(frames=batch.frames, frame_stride=batch.frame_stride, frame_ids=batch.frame_ids,
+                                 action=batch.action, reward=batch.reward, terminal=batch.is_terminal)
+        self.eng.learn_on_batch(cb)
+        if self.w["prioritized"]:
+            self.rb.update_device(batch, self.eng.priorities)
+        return batch
+
+
+def cpu_baseline(workload, seconds_budget=20.0):
+    """The oracle (torch-CPU fp32 restatement of the reference path: numpy PCG64 sampler (+ sum tree), uint8 stack
+    gather, forward/backward/Adam) timed on this box's host cores on a BOUNDED sample of the same workload."""
+    import numpy as np
+    import torch
+    from oracle.isdqn import iSDQN as Oracle
+    from oracle.replay_buffer import ReplayBuffer as ORB, ReplayElement
+    from oracle.samplers import PrioritizedSamplingDistribution as OP, UniformSamplingDistribution as OU
+
+    w = WORKLOADS[workload]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("ISDQN_CPU_BASELINE_THREADS", "16"))))  # a 1-GPU box's CPU share is 16 cores
+    torch.set_num_threads(cores)
+    cap = 1024  # bounded replay: the CPU step cost does not depend on the capacity (sampling is O(B log C))
+    rng = np.random.default_rng(0)
+    sampler = OP(0, cap) if w["prioritized"] else OU(0)
+    rb = ORB(sampler, w["B"], cap, stack_size=4, update_horizon=w["n"], gamma=0.99)
+    frames = rng.integers(0, 256, (cap + 8, 84, 84), dtype=np.uint8)
+    for i in range(cap):  # direct fill of the oracle's memory (one long stream), like prefill_synthetic
+        st = np.moveaxis(frames[i : i + 4], 0, -1)
+        nx = np.moveaxis(frames[i + w["n"] : i + w["n"] + 4], 0, -1)
+        rb._memory[i] = ReplayElement(st, int(rng.integers(0, w["n_actions"])), float(rng.choice([-1.0, 0.0, 1.0])), nx, False)
+        if w["prioritized"]:
+            sampler.add(i, float(rng.uniform(0.1, 2.0)))
+        else:
+            sampler.add(i)
+    rb.add_count = cap
+    agent = Oracle(0, (84, 84, 4), w["n_actions"], w["K"], list(FEATURES), True, False, "cnn", 6.25e-5, 0.99, w["n"], 1, 8000, adam_eps=1.5e-4)
+
+    def one():
+        batch = rb.sample()
+        agent.params, agent.optimizer_state, _ = agent.learn_on_batch(agent.params, agent.optimizer_state, batch)
+
+    one()  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 50:
+            break
+    return {"value": n / el, "unit": "gradient-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of the oracle (torch-CPU fp32 restatement) at B={w['B']}, K={w['K']}, replay of {cap} elements, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--capacity", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    w = WORKLOADS[args.workload]
+
+    rep = Replica(args.workload, args.capacity, args.precision, seed=rank, device=device)
+    for _ in range(args.warmup):
+        rep.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    # HIP events on the stream the kernels are launched on (torch's current stream is handed to the C ABI)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        rep.step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rep.rb._sampling_distribution._sum_tree.check_status() if w["prioritized"] else None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed_max = float(t.item())
+
+    if rank == 0:
+        dev_ms = sorted(a.elapsed_time(b) for a, b in ev)
+        dev_ms_avg = sum(dev_ms) / len(dev_ms)
+        bytes_step = algorithmic_bytes_per_step(w["B"], w["K"], w["n_actions"], w["prioritized"])
+        flops_step = algorithmic_flops_per_step(w["B"], w["K"], w["n_actions"])
+        achieved = bytes_step / (dev_ms_avg * 1e-3) / 1e9
+        out = {
+            "metric": "gradient-steps/sec (batch=256, K=9, 84x84x4)" if args.workload != "c5" else "gradient-steps/sec (batch=1024, K=32, 84x84x4)",
+            "value": world * args.steps / elapsed_max,
+            "unit": "gradient-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": w["desc"], "replay_capacity": args.capacity, "precision": args.precision,
+                       "replicas": world, "parallelism": f"independent-seed replicas x{world}"},
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "replay-sample -> Bellman-update step (all launches of one step; HIP-event time per step)",
+                "algorithmic_bytes_per_step": bytes_step, "device_ms_per_step_avg": dev_ms_avg,
+                "device_ms_per_step_p10_p50_p90": [dev_ms[len(dev_ms) // 10], dev_ms[len(dev_ms) // 2], dev_ms[(9 * len(dev_ms)) // 10]],
+                "mfma_util_vs_2.5PF": flops_step / (dev_ms_avg * 1e-3) / 2.5e15,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

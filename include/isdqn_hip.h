@@ -85,12 +85,15 @@ int isdqn_tree_query(const double* nodes, int32_t depth, const double* targets, 
  * the row gather below and, only for callers that want the reference's batch layout,
  * the stack materialisation. */
 
-/* Gather the element rows of `B` sampled element slots: frame ids [B][2*stack], action,
- * reward, terminal.  (itemgetter + np.stack of the scalar fields, replay_buffer.py:206-212) */
+/* Gather the element rows of `B` sampled elements: frame ids [B][2*stack], action, reward,
+ * terminal (itemgetter + np.stack of the scalar fields, replay_buffer.py:206-212).  `slots`
+ * are element slots, or -- when `index_to_slot` is not NULL -- the sampler's dense indices
+ * (samplers.py:43, :111), mapped through that table (the device copy of `_index_to_key`,
+ * samplers.py:45-49, reduced modulo the capacity). */
 int isdqn_replay_gather_rows(const int32_t* elem_frames, const int32_t* elem_action, const float* elem_reward,
-                             const uint8_t* elem_terminal, int32_t stack, const int32_t* slots, int32_t B,
-                             int32_t* out_frame_ids, int32_t* out_action, float* out_reward, uint8_t* out_terminal,
-                             void* stream);
+                             const uint8_t* elem_terminal, int32_t stack, const int32_t* index_to_slot,
+                             const int32_t* slots, int32_t B, int32_t* out_frame_ids, int32_t* out_action,
+                             float* out_reward, uint8_t* out_terminal, void* stream);
 
 /* Materialise ReplayElement.state / .next_state, each (B, h, w, stack) uint8 in the
  * reference's channel-last layout (replay_buffer.py:131-147 + np.stack :212). */
@@ -180,12 +183,14 @@ int isdqn_net_forward(const isdqn_net_config* cfg, const float* params, const ui
  * Bellman targets from heads 0..K-1 of the next states, squared TD loss on heads 1..K,
  * backward, Adam (in place on params / adam_m / adam_v; `adam_count` is a device int32
  * step counter incremented by the call).  Outputs (device): losses[K] = td.mean(axis=0)
- * (isdqn.py:103), and optionally q_values[B][K], targets[B][K] and priorities[B] (float64,
- * sqrt(mean_k td + 1e-10): the TD-error writeback the north star asks for; the reference
- * has no trainer wiring for it -- see DESIGN.md). */
+ * (isdqn.py:103); optionally losses_accum[K] += losses (the `cumulated_losses += losses` of
+ * update_online_params, isdqn.py:62, kept on the device so the step never synchronises),
+ * q_values[B][K], targets[B][K] and priorities[B] (float64, sqrt(mean_k td + 1e-10): the
+ * TD-error writeback the north star asks for; the reference has no trainer wiring for it --
+ * see DESIGN.md). */
 int isdqn_net_learn_on_batch(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v,
-                             int32_t* adam_count, const isdqn_batch* batch, float* losses, float* q_values,
-                             float* targets, double* priorities, void* workspace, void* stream);
+                             int32_t* adam_count, const isdqn_batch* batch, float* losses, float* losses_accum,
+                             float* q_values, float* targets, double* priorities, void* workspace, void* stream);
 
 /* Loss only, no update: iSDQN.loss_on_batch (isdqn.py:92-103). */
 int isdqn_net_loss_on_batch(const isdqn_net_config* cfg, const float* params, const isdqn_batch* batch, float* losses,

@@ -264,73 +264,108 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
     }
 }
 
-// Iterated Bellman target + squared TD loss (isdqn.py:92-109), one workgroup.
+// Iterated Bellman target + squared TD loss (isdqn.py:92-109).
 //   q_k(s,a) from head 1+k of the online rows, target_k = r + (1-terminal)*gamma^n*max_a' Q_k(s',a')
-//   from head k of the next-state rows (same parameters, stop-gradient), loss_k = mean_b td.
-// Also emits dL/dq (dout), its column sums (head bias gradient), priorities and bumps the Adam step.
-__global__ __launch_bounds__(1024) void head_loss_kernel(const float* __restrict__ q, int B, int K, int A, int nha_p,
-                                                         const int* __restrict__ action,
-                                                         const float* __restrict__ reward,
-                                                         const uint8_t* __restrict__ terminal, float gamma_n,
-                                                         float* __restrict__ dout, float* __restrict__ q_values,
-                                                         float* __restrict__ targets, float* __restrict__ losses,
-                                                         double* __restrict__ priorities, float* __restrict__ dbh,
-                                                         int* adam_count) {
-    __shared__ float s_red[16];
-    const int tid = threadIdx.x;
-    constexpr int MAXB = 4;  // B <= 4096
-    float td_sum[MAXB] = {0, 0, 0, 0};
-    if (dout != nullptr)
-        for (int i = tid; i < B * nha_p; i += 1024) dout[i] = 0.f;
-    __syncthreads();
+//   from head k of the next-state rows (same parameters, stop-gradient), td = (q - target)^2.
+// One workgroup per 64 transitions, wave w takes heads k = w, w+4, ...  Emits dL/dq rows (dout),
+// q_values/targets/priorities and per-workgroup partials of the per-head loss sums and of the head
+// bias gradient (column sums of dout); loss_finalize_kernel reduces them in a fixed order.
+constexpr int TD_ROWS = 64;
+__global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, int B, int K, int A, int nha_p,
+                                                 const int* __restrict__ action, const float* __restrict__ reward,
+                                                 const uint8_t* __restrict__ terminal, float gamma_n,
+                                                 float* __restrict__ dout, float* __restrict__ q_values,
+                                                 float* __restrict__ targets, double* __restrict__ priorities,
+                                                 float* __restrict__ loss_part, float* __restrict__ dbh_part) {
+    extern __shared__ float s_d[];  // [TD_ROWS][K] : 2*(q-target)/B ; then [TD_ROWS][K] td
+    __shared__ int s_action[TD_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * TD_ROWS;
+    const int b = b0 + lane;
+    const bool on = b < B;
+    float* s_td = s_d + TD_ROWS * K;
     const float inv_b = 1.f / (float)B;
-    for (int k = 0; k < K; ++k) {
-        float local = 0.f;
-#pragma unroll
-        for (int it = 0; it < MAXB; ++it) {
-            int b = tid + it * 1024;
-            if (b < B) {
-                int a = action[b];
-                float qv = q[(int64_t)b * nha_p + (1 + k) * A + a];
-                const float* nq = q + (int64_t)(B + b) * nha_p + k * A;
-                float mx = nq[0];
-                for (int j = 1; j < A; ++j) mx = fmaxf(mx, nq[j]);
-                float tg = reward[b] + (1.f - (float)terminal[b]) * gamma_n * mx;
-                float d = qv - tg;
-                float td = d * d;
-                if (q_values) q_values[(int64_t)b * K + k] = qv;
-                if (targets) targets[(int64_t)b * K + k] = tg;
-                if (dout) dout[(int64_t)b * nha_p + (1 + k) * A + a] = 2.f * d * inv_b;
-                td_sum[it] += td;
-                local += td;
-            }
+    if (dout != nullptr) {
+        const int rows = min(TD_ROWS, B - b0);
+        for (int i = tid; i < rows * nha_p; i += 256) dout[(int64_t)b0 * nha_p + i] = 0.f;
+    }
+    int a = 0;
+    float r = 0.f, nt = 0.f;
+    if (on) {
+        a = action[b];
+        r = reward[b];
+        nt = 1.f - (float)terminal[b];
+    }
+    if (wave == 0) s_action[lane] = on ? a : -1;
+    for (int k = wave; k < K; k += 4) {
+        float d = 0.f, td = 0.f;
+        if (on) {
+            float qv = q[(int64_t)b * nha_p + (1 + k) * A + a];
+            const float* nq = q + (int64_t)(B + b) * nha_p + k * A;
+            float mx = nq[0];
+            for (int j = 1; j < A; ++j) mx = fmaxf(mx, nq[j]);
+            float tg = r + nt * gamma_n * mx;
+            d = qv - tg;
+            td = d * d;
+            if (q_values) q_values[(int64_t)b * K + k] = qv;
+            if (targets) targets[(int64_t)b * K + k] = tg;
         }
-        for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
-        __syncthreads();
-        if ((tid & 63) == 0) s_red[tid >> 6] = local;
-        __syncthreads();
-        if (tid == 0) {
-            float s = 0.f;
-            for (int w = 0; w < 16; ++w) s += s_red[w];
-            losses[k] = s * inv_b;
+        s_d[lane * K + k] = 2.f * d * inv_b;
+        s_td[lane * K + k] = td;
+        float sum = td;
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if (lane == 0) loss_part[(int64_t)blockIdx.x * K + k] = sum;
+    }
+    __syncthreads();  // dout zero-fill (this workgroup's rows) and s_d / s_td complete
+    if (dout != nullptr) {
+        for (int i = tid; i < TD_ROWS * K; i += 256) {
+            int bl = i / K, k = i - bl * K;
+            if (b0 + bl < B) dout[(int64_t)(b0 + bl) * nha_p + (1 + k) * A + s_action[bl]] = s_d[i];
+        }
+        // column sums over this workgroup's rows: column (1+k)*A + a' collects rows whose action is a'
+        for (int c = tid; c < nha_p; c += 256) {
+            float sum = 0.f;
+            int head = c / A, aa = c - head * A;
+            if (head >= 1 && head <= K)
+                for (int bl = 0; bl < TD_ROWS; ++bl) sum += (s_action[bl] == aa) ? s_d[bl * K + head - 1] : 0.f;
+            dbh_part[(int64_t)blockIdx.x * nha_p + c] = sum;
         }
     }
-    if (priorities != nullptr) {
-#pragma unroll
-        for (int it = 0; it < MAXB; ++it) {
-            int b = tid + it * 1024;
-            if (b < B) priorities[b] = sqrt((double)(td_sum[it] / (float)K) + 1e-10);
-        }
+    if (priorities != nullptr && tid < TD_ROWS && b0 + tid < B) {
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += s_td[tid * K + k];
+        priorities[b0 + tid] = sqrt((double)(sum / (float)K) + 1e-10);
     }
-    __syncthreads();
-    if (dbh != nullptr && dout != nullptr) {
-        for (int c = tid; c < nha_p; c += 1024) {
+}
+
+// losses[k] = mean_b td (isdqn.py:103), optional running sum (update_online_params' cumulated_losses,
+// isdqn.py:62, kept on the device), head-bias gradient, Adam step counter and bias corrections.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ loss_part,
+                                                            const float* __restrict__ dbh_part, int n_blk, int B, int K,
+                                                            int nha_p, float* __restrict__ losses,
+                                                            float* __restrict__ loss_accum, float* __restrict__ dbh,
+                                                            int* adam_count, float b1, float b2,
+                                                            float* __restrict__ adam_consts) {
+    const int tid = threadIdx.x;
+    for (int k = tid; k < K; k += 256) {
+        float s = 0.f;
+        for (int i = 0; i < n_blk; ++i) s += loss_part[(int64_t)i * K + k];
+        s /= (float)B;
+        losses[k] = s;
+        if (loss_accum != nullptr) loss_accum[k] += s;
+    }
+    if (dbh != nullptr)
+        for (int c = tid; c < nha_p; c += 256) {
             float s = 0.f;
-            for (int b = 0; b < B; ++b) s += dout[(int64_t)b * nha_p + c];
+            for (int i = 0; i < n_blk; ++i) s += dbh_part[(int64_t)i * nha_p + c];
             dbh[c] = s;
         }
+    if (adam_count != nullptr && tid == 0) {
+        int t = *adam_count + 1;
+        *adam_count = t;
+        adam_consts[0] = (float)(1.0 - pow((double)b1, (double)t));
+        adam_consts[1] = (float)(1.0 - pow((double)b2, (double)t));
     }
-    if (adam_count != nullptr && tid == 0) *adam_count = *adam_count + 1;
 }
 
 // Adam (optax.adam, isdqn.py:46, 85-86) over the flat parameter buffer; the gradient of every
@@ -347,19 +382,12 @@ struct AdamTable {
     int n, total_blocks;
 };
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* __restrict__ p, float* __restrict__ m,
-                                                   float* __restrict__ v, const int* __restrict__ count, float lr,
+                                                   float* __restrict__ v, const float* __restrict__ consts, float lr,
                                                    float b1, float b2, float eps, float* __restrict__ grad_out) {
-    __shared__ float s_c[2];
     int e = 0;
     while (e + 1 < tab.n && (int)blockIdx.x >= tab.e[e + 1].block_start) ++e;
     const AdamEntry en = tab.e[e];
-    if (threadIdx.x == 0) {
-        double t = (double)(*count);
-        s_c[0] = (float)(1.0 - pow((double)b1, t));
-        s_c[1] = (float)(1.0 - pow((double)b2, t));
-    }
-    __syncthreads();
-    const float c1 = s_c[0], c2 = s_c[1];
+    const float c1 = consts[0], c2 = consts[1];  // 1 - b1^t, 1 - b2^t (loss_finalize_kernel)
     int64_t i = ((int64_t)(blockIdx.x - en.block_start) * 256 + threadIdx.x) * 4;
     if (i >= en.size) return;
     float4 g = *reinterpret_cast<const float4*>(en.g + i);
@@ -707,8 +735,8 @@ extern "C" int isdqn_net_forward(const isdqn_net_config* cfg, const float* param
 }
 
 static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v, int32_t* adam_count,
-                         const isdqn_batch* batch, float* losses, float* q_values, float* targets, double* priorities,
-                         void* workspace, void* stream, bool learn, float* grad_out) {
+                         const isdqn_batch* batch, float* losses, float* loss_accum, float* q_values, float* targets,
+                         double* priorities, void* workspace, void* stream, bool learn, float* grad_out) {
     Plan P;
     int rc = build_plan(cfg, P);
     if (rc) return rc;
@@ -732,9 +760,17 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     // ---- targets, loss, dL/dq ----
     float* qv = q_values ? q_values : ws + P.qv_off;
     float* tg = targets ? targets : ws + P.tg_off;
-    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(1024), 0, st, ws + P.q_off, B, K, P.n_actions, P.nha_p,
-                       batch->action, batch->reward, batch->terminal, cfg->gamma_n, learn ? ws + P.dout_off : nullptr,
-                       qv, tg, losses, priorities, learn ? ws + P.dbh_off : nullptr, learn ? adam_count : nullptr);
+    const int n_blk = ceil_div(B, TD_ROWS);
+    float* loss_part = ws + P.lpart_off;
+    float* dbh_part = loss_part + (int64_t)n_blk * K;
+    float* adam_consts = ws + P.adam_tab_off;
+    hipLaunchKernelGGL(td_kernel, dim3(n_blk), dim3(256), 2 * TD_ROWS * K * sizeof(float), st, ws + P.q_off, B, K,
+                       P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n,
+                       learn ? ws + P.dout_off : nullptr, qv, tg, priorities, loss_part, dbh_part);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p, losses,
+                       loss_accum, learn ? ws + P.dbh_off : nullptr, learn ? adam_count : nullptr, cfg->adam_b1,
+                       cfg->adam_b2, adam_consts);
     ISDQN_HIP_CHECK(hipGetLastError());
     if (!learn) return ISDQN_OK;
 
@@ -806,32 +842,33 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         }
     }
     tab.total_blocks = blocks;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, tab, params, adam_m, adam_v, adam_count,
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, tab, params, adam_m, adam_v, ws + P.adam_tab_off,
                        cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps, grad_out);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
 }
 
 extern "C" int isdqn_net_learn_on_batch(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v,
-                                        int32_t* adam_count, const isdqn_batch* batch, float* losses, float* q_values,
-                                        float* targets, double* priorities, void* workspace, void* stream) {
-    return learn_or_loss(cfg, params, adam_m, adam_v, adam_count, batch, losses, q_values, targets, priorities,
-                         workspace, stream, true, nullptr);
+                                        int32_t* adam_count, const isdqn_batch* batch, float* losses,
+                                        float* losses_accum, float* q_values, float* targets, double* priorities,
+                                        void* workspace, void* stream) {
+    return learn_or_loss(cfg, params, adam_m, adam_v, adam_count, batch, losses, losses_accum, q_values, targets,
+                         priorities, workspace, stream, true, nullptr);
 }
 
 // Test hook (not in the public header): learn_on_batch that also writes the reduced gradient (internal layout).
 extern "C" int isdqn_net_learn_on_batch_debug(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v,
                                               int32_t* adam_count, const isdqn_batch* batch, float* losses,
-                                              float* q_values, float* targets, double* priorities, void* workspace,
-                                              void* stream, float* grad_out) {
-    return learn_or_loss(cfg, params, adam_m, adam_v, adam_count, batch, losses, q_values, targets, priorities,
-                         workspace, stream, true, grad_out);
+                                              float* losses_accum, float* q_values, float* targets, double* priorities,
+                                              void* workspace, void* stream, float* grad_out) {
+    return learn_or_loss(cfg, params, adam_m, adam_v, adam_count, batch, losses, losses_accum, q_values, targets,
+                         priorities, workspace, stream, true, grad_out);
 }
 
 extern "C" int isdqn_net_loss_on_batch(const isdqn_net_config* cfg, const float* params, const isdqn_batch* batch,
                                        float* losses, float* q_values, float* targets, void* workspace, void* stream) {
-    return learn_or_loss(cfg, const_cast<float*>(params), nullptr, nullptr, nullptr, batch, losses, q_values, targets,
-                         nullptr, workspace, stream, false, nullptr);
+    return learn_or_loss(cfg, const_cast<float*>(params), nullptr, nullptr, nullptr, batch, losses, nullptr, q_values,
+                         targets, nullptr, workspace, stream, false, nullptr);
 }
 
 extern "C" int isdqn_net_shift_params(const isdqn_net_config* cfg, float* params, void* stream) {

@@ -43,7 +43,7 @@ struct Plan {
     int n_heads, n_actions, nha, nha_p;
     int64_t n_params;
     // workspace (float offsets unless noted)
-    int64_t q_off, dout_off, da_off, slab_off, qv_off, tg_off, dbh_off, adam_tab_off;
+    int64_t q_off, dout_off, da_off, slab_off, qv_off, tg_off, dbh_off, adam_tab_off, lpart_off;
     int64_t slab_floats, da_floats;
     int64_t ws_bytes;
     std::vector<std::pair<std::string, std::pair<int64_t, int64_t>>> regions;  // name -> (byte offset, byte size)
@@ -216,7 +216,8 @@ static inline int build_plan(const isdqn_net_config* cfg, Plan& P) {
     P.qv_off = region("q_values", (int64_t)P.B * (P.n_heads - 1));
     P.tg_off = region("targets", (int64_t)P.B * (P.n_heads - 1));
     P.dbh_off = region("dbh", P.nha_p);
-    P.adam_tab_off = region("adam_table", 4096);
+    P.adam_tab_off = region("adam_consts", 64);
+    P.lpart_off = region("loss_partials", (int64_t)ceil_div(P.B, 64) * (P.n_heads - 1 + P.nha_p));
     P.ws_bytes = off * 4;
     return ISDQN_OK;
 }

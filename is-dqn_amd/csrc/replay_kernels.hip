@@ -14,6 +14,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int* __restrict_
                                                           const int* __restrict__ elem_action,
                                                           const float* __restrict__ elem_reward,
                                                           const uint8_t* __restrict__ elem_terminal, int stack2,
+                                                          const int* __restrict__ index_to_slot,
                                                           const int* __restrict__ slots, int B,
                                                           int* __restrict__ out_ids, int* __restrict__ out_action,
                                                           float* __restrict__ out_reward,
@@ -22,6 +23,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int* __restrict_
     if (i >= B * stack2) return;
     int b = i / stack2, c = i - b * stack2;
     int slot = slots[b];
+    if (index_to_slot != nullptr) slot = index_to_slot[slot];
     out_ids[i] = elem_frames[(int64_t)slot * stack2 + c];
     if (c == 0) {
         out_action[b] = elem_action[slot];
@@ -65,7 +67,8 @@ using namespace isdqn;
 
 extern "C" int isdqn_replay_gather_rows(const int32_t* elem_frames, const int32_t* elem_action,
                                         const float* elem_reward, const uint8_t* elem_terminal, int32_t stack,
-                                        const int32_t* slots, int32_t B, int32_t* out_frame_ids, int32_t* out_action,
+                                        const int32_t* index_to_slot, const int32_t* slots, int32_t B,
+                                        int32_t* out_frame_ids, int32_t* out_action,
                                         float* out_reward, uint8_t* out_terminal, void* stream) {
     ISDQN_REQUIRE(elem_frames && elem_action && elem_reward && elem_terminal && slots, ISDQN_ERR_ARG, "null pointer");
     ISDQN_REQUIRE(out_frame_ids && out_action && out_reward && out_terminal, ISDQN_ERR_ARG, "null pointer");
@@ -73,7 +76,7 @@ extern "C" int isdqn_replay_gather_rows(const int32_t* elem_frames, const int32_
     if (B == 0) return ISDQN_OK;
     int total = B * 2 * stack;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, elem_frames,
-                       elem_action, elem_reward, elem_terminal, 2 * stack, slots, B, out_frame_ids, out_action,
+                       elem_action, elem_reward, elem_terminal, 2 * stack, index_to_slot, slots, B, out_frame_ids, out_action,
                        out_reward, out_terminal);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;

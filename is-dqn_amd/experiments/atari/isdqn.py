@@ -1,0 +1,92 @@
+"""iS-DQN on Atari: the reference's entry point (experiments/atari/isdqn.py:15-48) on the HIP engine.
+
+    python experiments/atari/isdqn.py -en L2_K9_LN1_cnn_Asterix -s 1 -f 32 64 64 512 -at cnn -ln -nbi 9 ...
+
+``experiment_name`` must end in ``_<Game>``; outputs go under experiments/atari/exp_output/<name>/isdqn/.
+"""
+import os
+import sys
+
+_PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+import numpy as np
+
+from experiments.base.dqn import train
+from experiments.base.utils import prepare_logs
+from slimdqn.networks.isdqn import iSDQN
+from slimdqn.sample_collection.replay_buffer import ReplayBuffer
+from slimdqn.sample_collection.samplers import PrioritizedSamplingDistribution, UniformSamplingDistribution
+
+
+def run(argvs=sys.argv[1:], root=None):
+    p = prepare_logs("atari", "isdqn", argvs, root=root)
+    rng = np.random.default_rng(p["seed"])
+    q_seed, train_seed = (int(s) for s in rng.integers(0, 2**31 - 1, size=2))
+
+    game = p["experiment_name"].split("_")[-1]
+    if p["env_backend"] == "synthetic":
+        from slimdqn.environments.synthetic import SyntheticAtariEnv
+
+        env = SyntheticAtariEnv(game, seed=p["seed"])
+    else:
+        from slimdqn.environments.atari import AtariEnv
+
+        env = AtariEnv(game)
+    if p["prioritized"]:
+        sampler = PrioritizedSamplingDistribution(p["seed"], p["replay_buffer_capacity"])
+    else:
+        sampler = UniformSamplingDistribution(p["seed"])
+    rb = ReplayBuffer(
+        sampling_distribution=sampler,
+        max_capacity=p["replay_buffer_capacity"],
+        batch_size=p["batch_size"],
+        update_horizon=p["update_horizon"],
+        gamma=p["gamma"],
+        clipping=lambda x: np.clip(x, -1, 1),
+        stack_size=4,
+        compress=True,
+    )
+    agent = iSDQN(
+        q_seed,
+        (env.state_height, env.state_width, env.n_stacked_frames),
+        env.n_actions,
+        n_bellman_iterations=p["n_bellman_iterations"],
+        features=p["features"],
+        layer_norm=p["layer_norm"],
+        batch_norm=p["batch_norm"],
+        architecture_type=p["architecture_type"],
+        learning_rate=p["learning_rate"],
+        gamma=p["gamma"],
+        update_horizon=p["update_horizon"],
+        data_to_update=p["data_to_update"],
+        target_update_frequency=p["target_update_frequency"],
+        adam_eps=1.5e-4,
+        batch_size=p["batch_size"],
+        precision=p["precision"],
+    )
+    if p["prioritized"]:
+        _wire_prioritized(agent, rb)
+    return train(np.random.default_rng(train_seed), p, agent, env, rb)
+
+
+def _wire_prioritized(agent, rb):
+    """Trainer wiring the reference does not have: new elements enter with the
+    largest priority seen so far (Dopamine's convention), sampled elements get sqrt(mean_k td) written back."""
+    tree = rb._sampling_distribution._sum_tree
+    plain_add = rb.add
+    rb.add = lambda transition, **kw: plain_add(transition, priority=kw.get("priority", tree.max_recorded_priority))
+    plain_update = agent.update_online_params
+
+    def update_online_params(step, replay_buffer):
+        if step % agent.data_to_update == 0:
+            batch = replay_buffer.sample()
+            agent.params, agent.optimizer_state, _ = agent.learn_on_batch(agent.params, agent.optimizer_state, batch)
+            replay_buffer.update_device(batch, agent._engine.priorities)
+
+    agent.update_online_params = update_online_params
+
+
+if __name__ == "__main__":
+    run()

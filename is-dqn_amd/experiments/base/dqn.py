@@ -1,0 +1,76 @@
+"""The training loop with the reference's cadence (experiments/base/dqn.py:13-85), JAX-free.
+
+Per environment step: epsilon-greedy action -> env.step -> replay add; once more than ``n_initial_samples``
+steps were collected, ``update_online_params`` (a gradient step every ``data_to_update`` steps) and
+``update_target_params`` (head shift + loss logs every ``target_update_frequency`` steps).  An epoch ends
+after ``n_training_steps_per_epoch`` steps at the next episode boundary; per epoch the returns are saved and
+the model is kept when the epoch's average return is the best so far.
+
+One process drives one GPU; with torch.distributed initialised (one seed/game per rank, launched by
+experiments/launch.py) the only communication is an all_gather of a few per-epoch scalars.
+"""
+import numpy as np
+
+from experiments.base.utils import save_data
+from slimdqn.sample_collection.utils import collect_single_sample, linear_schedule
+
+
+def _gather_epoch_metrics(metrics: np.ndarray):
+    """all_gather of the per-epoch metric vector over RCCL (xGMI); identity when not distributed."""
+    try:
+        import torch
+        import torch.distributed as dist
+    except ImportError:  # pragma: no cover
+        return metrics[None]
+    if not (dist.is_available() and dist.is_initialized()):
+        return metrics[None]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor(metrics, dtype=torch.float32, device=dev)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return torch.stack(out).cpu().numpy()
+
+
+def train(key, p: dict, agent, env, rb):
+    """``key``: a numpy Generator (the reference threads a jax PRNGKey through the loop, dqn.py:34)."""
+    rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+    epsilon_schedule = linear_schedule(1.0, p["epsilon_end"], p["epsilon_duration"])
+    n_training_steps = 0
+    env.reset()
+    returns, lengths = [[0]], [[0]]
+    best_avg_return = -float("inf")
+    gathered = []
+
+    for idx_epoch in range(p["n_epochs"]):
+        steps_in_epoch, has_reset = 0, False
+        while steps_in_epoch < p["n_training_steps_per_epoch"] or not has_reset:
+            reward, has_reset = collect_single_sample(rng, env, agent, rb, p, epsilon_schedule, n_training_steps)
+            steps_in_epoch += 1
+            n_training_steps += 1
+            returns[idx_epoch][-1] += reward
+            lengths[idx_epoch][-1] += 1
+            if has_reset and steps_in_epoch < p["n_training_steps_per_epoch"]:
+                returns[idx_epoch].append(0)
+                lengths[idx_epoch].append(0)
+            if n_training_steps > p["n_initial_samples"]:
+                agent.update_online_params(n_training_steps, rb)
+                updated, logs = agent.update_target_params(n_training_steps)
+                if updated:
+                    p["wandb"].log({"n_training_steps": n_training_steps, **logs})
+
+        avg_return = float(np.mean(returns[idx_epoch]))
+        avg_length = float(np.mean(lengths[idx_epoch]))
+        print(f"\nEpoch {idx_epoch}: Return {avg_return} averaged on {len(lengths[idx_epoch])} episodes.\n", flush=True)
+        p["wandb"].log({"epoch": idx_epoch, "n_training_steps": n_training_steps, "avg_return": avg_return,
+                        "avg_length_episode": avg_length})
+        gathered.append(_gather_epoch_metrics(np.asarray([avg_return, avg_length, n_training_steps], np.float32)))
+
+        model = None
+        if avg_return > best_avg_return:
+            best_avg_return = avg_return
+            model = agent.get_model()
+        if idx_epoch < p["n_epochs"] - 1:
+            returns.append([0])
+            lengths.append([0])
+        save_data(p, returns, lengths, model)
+    return gathered

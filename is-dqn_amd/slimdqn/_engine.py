@@ -91,6 +91,7 @@ class QNetEngine:
             self.adam_count = torch.zeros(1, dtype=torch.int32, device=self.device)
             K = self.n_heads - 1
             self.losses = torch.zeros(K, dtype=torch.float32, device=self.device)
+            self.losses_accum = torch.zeros(K, dtype=torch.float32, device=self.device)
             self.q_values = torch.zeros(batch_size, K, dtype=torch.float32, device=self.device)
             self.targets = torch.zeros(batch_size, K, dtype=torch.float32, device=self.device)
             self.priorities = torch.zeros(batch_size, dtype=torch.float64, device=self.device)
@@ -242,7 +243,7 @@ class QNetEngine:
         """One gradient step in place; returns the device tensor of per-head losses (no sync)."""
         args = [
             ctypes.byref(self.cfg), _hip.ptr(self.params), _hip.ptr(self.adam_m), _hip.ptr(self.adam_v),
-            _hip.ptr(self.adam_count), ctypes.byref(batch), _hip.ptr(self.losses), _hip.ptr(self.q_values),
+            _hip.ptr(self.adam_count), ctypes.byref(batch), _hip.ptr(self.losses), _hip.ptr(self.losses_accum), _hip.ptr(self.q_values),
             _hip.ptr(self.targets), _hip.ptr(self.priorities), _hip.ptr(self.workspace), _hip.stream_ptr(),
         ]
         if grad_out is None:

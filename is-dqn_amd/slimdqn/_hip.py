@@ -79,7 +79,7 @@ _SIGNATURES = {
     "isdqn_tree_query": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "isdqn_replay_gather_rows": (
         c_int32,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "isdqn_replay_materialize": (
         c_int32,
@@ -101,11 +101,11 @@ _SIGNATURES = {
     ),
     "isdqn_net_learn_on_batch": (
         c_int32,
-        [POINTER(NetConfig), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+        [POINTER(NetConfig), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "isdqn_net_learn_on_batch_debug": (
         c_int32,
-        [POINTER(NetConfig), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+        [POINTER(NetConfig), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "isdqn_net_loss_on_batch": (
         c_int32,
@@ -132,6 +132,10 @@ def lib() -> ctypes.CDLL:
     """The loaded C-ABI library; fails loudly when the HIP extension has not been built."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm bundles its own libamdhip64; import it first so that this library binds to the SAME HIP
+        # runtime (streams and device pointers are shared with torch) instead of loading a second one.
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first (python is-dqn_amd/build.py). "

@@ -1,0 +1,142 @@
+"""Sampling distributions with the reference's surface (slimdqn/sample_collection/samplers.py).
+
+Host side (python, like the reference): the PCG64 generator and the key <-> dense-index maps with
+swap-with-last removal (samplers.py:13-49).  Device side: the float64 sum tree of the prioritized
+distribution (csrc/tree_kernels.hip) and an index -> element-slot table so that a sampled batch
+never leaves the GPU:
+
+    sample_device(size)  ->  int32 device tensor of dense indices   (no synchronisation)
+    sample(size)         ->  int32 numpy keys, exactly the reference's return value
+
+Both consume the generator identically (``integers(len, size)`` / ``uniform(0, root, size)`` which is
+``root * random(size)`` bit for bit), so a run can mix them freely and stay on the reference's stream.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from slimdqn import _hip
+from slimdqn.sample_collection import sum_tree
+
+
+class UniformSamplingDistribution:
+    """samplers.py:13-49."""
+
+    def __init__(self, seed: int, device: str = "cuda:0") -> None:
+        self._rng_key = np.random.default_rng(seed)
+        self._key_to_index = {}
+        self._index_to_key = []
+        self.device = torch.device(device)
+        self._pin = None
+
+    # -- bookkeeping -----------------------------------------------------------------------------
+    def add(self, key) -> None:
+        self._key_to_index[key] = len(self._index_to_key)
+        self._index_to_key.append(key)
+
+    def add_bulk(self, keys, priorities=None) -> None:
+        """Vectorised ``add`` for consecutive fresh keys (synthetic prefill); same resulting maps."""
+        start = len(self._index_to_key)
+        keys = [int(k) for k in keys]
+        self._index_to_key.extend(keys)
+        self._key_to_index.update({k: start + i for i, k in enumerate(keys)})
+
+    def remove(self, key) -> None:
+        assert key in self._key_to_index, ValueError(f"Key {key} not found.")
+        hole = self._key_to_index.pop(key)
+        last_key = self._index_to_key.pop()
+        if last_key != key:
+            self._index_to_key[hole] = last_key
+            self._key_to_index[last_key] = hole
+
+    def __len__(self) -> int:
+        return len(self._index_to_key)
+
+    # -- sampling ----------------------------------------------------------------------------------
+    def _draw_indices(self, size: int) -> np.ndarray:
+        assert self._index_to_key, ValueError("No keys to sample from.")
+        return self._rng_key.integers(len(self._index_to_key), size=size)
+
+    def sample(self, size: int):
+        indices = self._draw_indices(size)
+        i2k = self._index_to_key
+        return np.fromiter((i2k[i] for i in indices), dtype=np.int32, count=size)
+
+    def _to_device(self, host: np.ndarray, dtype) -> torch.Tensor:
+        # pageable -> device copy: the host array may be reused as soon as this returns (no pinned-buffer race)
+        return torch.from_numpy(np.ascontiguousarray(host)).to(self.device).to(dtype)
+
+    def sample_device(self, size: int) -> torch.Tensor:
+        """Dense indices on the device (int32); the draw is the reference's ``integers(len, size)``."""
+        return self._to_device(self._draw_indices(size).astype(np.int32), torch.int32)
+
+    def keys_of(self, indices: np.ndarray) -> np.ndarray:
+        i2k = self._index_to_key
+        return np.fromiter((i2k[i] for i in indices), dtype=np.int32, count=len(indices))
+
+
+class PrioritizedSamplingDistribution(UniformSamplingDistribution):
+    """samplers.py:52-116 with the sum tree resident on the GPU."""
+
+    def __init__(self, seed: int, max_capacity: int, priority_exponent: float = 1.0, device: str = "cuda:0") -> None:
+        self._max_capacity = max_capacity
+        self._priority_exponent = priority_exponent
+        self._sum_tree = sum_tree.SumTree(self._max_capacity, device=device)
+        super().__init__(seed=seed, device=device)
+
+    def _transform(self, priority):
+        return 0.0 if priority == 0.0 else priority**self._priority_exponent
+
+    def add(self, key, priority) -> None:
+        super().add(key)
+        if priority is None:
+            priority = 0.0
+        value = float(self._transform(priority))
+        assert value >= 0.0, "Values must be positive."
+        # one-leaf set on the device, no synchronisation (the value was validated on the host)
+        idx = torch.tensor([self._key_to_index[key]], dtype=torch.int32, device=self.device)
+        val = torch.tensor([value], dtype=torch.float64, device=self.device)
+        self._sum_tree.set_device(idx, val)
+
+    def add_bulk(self, keys, priorities=None) -> None:
+        start = len(self._index_to_key)
+        super().add_bulk(keys)
+        pr = np.zeros(len(keys)) if priorities is None else np.asarray(priorities, np.float64)
+        pr = np.where(pr == 0.0, 0.0, pr**self._priority_exponent)
+        self._sum_tree.set(np.arange(start, start + len(keys), dtype=np.int32), pr)
+
+    def update(self, keys, priorities) -> None:
+        if not isinstance(keys, np.ndarray):
+            keys = np.asarray([keys], dtype=np.int32)
+        priorities = np.where(priorities == 0.0, 0.0, priorities**self._priority_exponent)
+        k2i = self._key_to_index
+        self._sum_tree.set(np.fromiter((k2i[k] for k in keys.tolist()), dtype=np.int32), priorities)
+
+    def update_device(self, indices: torch.Tensor, priorities: torch.Tensor) -> None:
+        """TD-error writeback without leaving the GPU: ``indices`` are the dense indices returned by
+        ``sample_device`` (the leaves of the tree), ``priorities`` float64.  exponent 1.0 keeps the
+        values bit-identical to what ``update`` would write; other exponents are applied here with
+        torch's float64 pow (not part of the bit-exact contract, like the reference's own libm pow)."""
+        if self._priority_exponent != 1.0:
+            priorities = torch.where(priorities == 0.0, priorities, priorities**self._priority_exponent)
+        self._sum_tree.set_device(indices, priorities)
+
+    def remove(self, key) -> None:
+        index = self._key_to_index[key]
+        last_index = len(self._index_to_key) - 1
+        self._sum_tree.swap_remove_device(index, last_index)  # samplers.py:92-102 on the device
+        super().remove(key)
+
+    def sample(self, size: int):
+        if self._sum_tree.root == 0.0:
+            # reference samplers.py:106-108 calls ``.keys`` on an ndarray here -> AttributeError (kept)
+            return super().sample(size).keys
+        indices = self.sample_device(size).cpu().numpy()
+        self._sum_tree.check_status()
+        return self.keys_of(indices)
+
+    def sample_device(self, size: int) -> torch.Tensor:
+        unit = self._rng_key.random(size)  # uniform(0, root, size) == 0.0 + root * random(size)
+        u = self._to_device(unit, torch.float64)
+        return self._sum_tree.query_device(u, unit=True)

@@ -1,0 +1,131 @@
+"""GPU tests of the drop-in agent surface (slimdqn.networks.isdqn.iSDQN on the HIP engine) and of the
+trainer loop: cadence of update_online_params / update_target_params (isdqn.py:55-80), parity of a short
+training run against the oracle agent fed by the oracle replay on the same seed, reference-layout batches,
+and the experiments/atari/isdqn.py entry point end to end on the synthetic environment."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FEATS = (8, 12, 16, 24)
+
+
+def _agents(K=3, A=5, B=8, T=6, utd=2, lr=1e-3, n=1):
+    from oracle.isdqn import iSDQN as Oracle
+    from slimdqn.networks.isdqn import iSDQN
+    from tests.gpu_helpers import perturbed_params
+
+    params = perturbed_params(4, (84, 84, 4), FEATS, "cnn", (1 + K) * A, True)
+    hip = iSDQN(0, (84, 84, 4), A, K, list(FEATS), True, False, "cnn", lr, 0.99, n, utd, T, adam_eps=1.5e-4, batch_size=B)
+    hip._engine.import_flax(params)
+    ora = Oracle(0, (84, 84, 4), A, K, list(FEATS), True, False, "cnn", lr, 0.99, n, utd, T, adam_eps=1.5e-4, params=params)
+    return hip, ora
+
+
+def test_training_run_matches_oracle_agent_and_replay():
+    from oracle.replay_buffer import ReplayBuffer as ORB, TransitionElement as OT
+    from oracle.samplers import UniformSamplingDistribution as OU
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+
+    K, A, B, T, utd = 3, 5, 8, 6, 2
+    hip, ora = _agents(K, A, B, T, utd)
+    rb = ReplayBuffer(UniformSamplingDistribution(3), B, 100, update_horizon=1, gamma=0.99)
+    orb = ORB(OU(3), B, 100, update_horizon=1, gamma=0.99)
+    rng = np.random.default_rng(0)
+    logs_h, logs_o = [], []
+    for step in range(1, 41):
+        obs = rng.integers(0, 256, (84, 84), dtype=np.uint8)
+        a, r, term = int(rng.integers(0, A)), float(rng.choice([-1.0, 0.0, 1.0])), bool(rng.random() < 0.05)
+        rb.add(TransitionElement(obs, a, r, term, term))
+        orb.add(OT(obs, a, r, term, term))
+        if step > 12:
+            hip.update_online_params(step, rb)
+            ora.update_online_params(step, orb)
+            uh, lh = hip.update_target_params(step)
+            uo, lo = ora.update_target_params(step)
+            assert uh == uo
+            if uh:
+                logs_h.append(lh)
+                logs_o.append(lo)
+    assert len(logs_h) >= 4
+    for lh, lo in zip(logs_h, logs_o):
+        assert lh.keys() == lo.keys()
+        for k in lh:
+            assert abs(lh[k] - lo[k]) < 2e-3 * max(1.0, abs(lo[k])), (k, lh[k], lo[k])
+    got = hip.get_model()["params"]
+    exp = ora.get_model()["params"]
+    for mod in exp:
+        for leaf in exp[mod]:
+            assert got[mod][leaf].shape == exp[mod][leaf].shape
+            assert np.abs(got[mod][leaf] - exp[mod][leaf]).max() < 2e-3, (mod, leaf)
+
+
+def test_reference_layout_batches_and_functional_signatures():
+    """learn_on_batch / loss_on_batch accept ReplayElement-style batches with (B,84,84,4) uint8 stacks and a
+    Flax-layout pytree, like the reference's jitted methods (isdqn.py:82-103)."""
+    from oracle.replay_buffer import ReplayElement
+
+    K, A, B = 3, 5, 8
+    hip, ora = _agents(K, A, B)
+    rng = np.random.default_rng(1)
+    s = ReplayElement(state=rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8), action=rng.integers(0, A, B),
+                      reward=rng.normal(size=B), next_state=rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8),
+                      is_terminal=rng.integers(0, 2, B))
+    loss_h, (per_head_h, _) = hip.loss_on_batch(hip.params, s)
+    loss_o, (per_head_o, _) = ora.loss_on_batch(ora.params, s)
+    assert abs(float(loss_h) - float(loss_o)) < 1e-3 * max(1.0, abs(float(loss_o)))
+    np.testing.assert_allclose(per_head_h.cpu().numpy(), per_head_o.detach().numpy(), atol=1e-3)
+    # a pytree handed in from outside is honoured
+    tree = ora.get_model()
+    loss_t, _ = hip.loss_on_batch(tree, s)
+    assert abs(float(loss_t) - float(loss_o)) < 1e-3 * max(1.0, abs(float(loss_o)))
+    p, st, losses = hip.learn_on_batch(hip.params, hip.optimizer_state, s)
+    assert p is hip.params and losses.shape == (K,)
+    # shift on an external copy leaves the agent's parameters alone (shift_params is functional in the reference)
+    before = hip.get_model()["params"]["Dense_1"]["bias"].copy()
+    shifted = hip.shift_params(hip.params.clone())
+    np.testing.assert_array_equal(hip.get_model()["params"]["Dense_1"]["bias"], before)
+    np.testing.assert_array_equal(shifted["params"]["Dense_1"]["bias"][:-A], before[A:])
+    # compute_target formula (test_isdqn.py:51-63)
+    nq = torch.randn(K, A)
+    one = ReplayElement(None, 0, 0.7, None, 0)
+    tgt = hip.compute_target(one, nq)
+    np.testing.assert_allclose(tgt.numpy(), 0.7 + 0.99 * nq.max(-1).values.numpy(), rtol=1e-6)
+
+
+def test_best_action_follows_head_choice():
+    K, A, B = 3, 5, 8
+    hip, ora = _agents(K, A, B)
+    state = np.random.default_rng(2).integers(0, 256, (84, 84, 4)).astype(np.float32)  # env.state is float32
+    q = hip.q_values(hip.params, state)
+    for idx in range(K):
+        assert hip.best_action(hip.params, state, key=idx) == int(np.argmax(q[1 + idx]))
+        assert hip.best_action(hip.params, state, key=idx) == ora.best_action(ora.params, state.astype(np.uint8), idx)
+    assert 0 <= hip.best_action(hip.params, state) < A
+
+
+@pytest.mark.parametrize("prioritized", [False, True])
+def test_entry_point_end_to_end_on_synthetic_env(tmp_path, prioritized):
+    from experiments.atari.isdqn import run
+
+    argv = ["-en", "smoke_Synthetic", "-s", "1", "-dw", "-f", "8", "8", "8", "16", "-rbc", "200", "-bs", "8", "-n", "3" if prioritized else "1",
+            "-horizon", "50", "-at", "cnn", "-ne", "2", "-ntspe", "60", "-utd", "4", "-nis", "20", "-ed", "100", "-nbi", "2", "-ln",
+            "-tuf", "16", "-env", "synthetic"] + (["-per"] if prioritized else [])
+    gathered = run(argv, root=str(tmp_path))
+    assert len(gathered) == 2 and gathered[0].shape == (1, 3)
+    out = tmp_path / "atari" / "exp_output" / "smoke_Synthetic"
+    params = json.load(open(out / "parameters.json"))
+    assert params["shared_parameters"]["features"] == [8, 8, 8, 16] and params["isdqn"]["n_bellman_iterations"] == 2
+    res = json.load(open(out / "isdqn" / "episode_returns_and_lengths" / "1.json"))
+    assert len(res["episode_returns"]) == 2
+    model = pickle.load(open(out / "isdqn" / "models" / "1", "rb"))
+    assert model["params"]["Conv_0"]["kernel"].shape == (8, 8, 4, 8)
+    assert model["params"]["Dense_1"]["kernel"].shape == (16, 3 * 9)
+    with pytest.raises(AssertionError):  # same seed again: refused (experiments/base/utils.py:46-51)
+        run(argv, root=str(tmp_path))

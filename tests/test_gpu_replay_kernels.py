@@ -25,7 +25,7 @@ def test_gather_materialize_deinterleave_round_trip():
     act = torch.empty(B, dtype=torch.int32, device="cuda")
     rew = torch.empty(B, dtype=torch.float32, device="cuda")
     ter = torch.empty(B, dtype=torch.uint8, device="cuda")
-    _hip.check(lib.isdqn_replay_gather_rows(_hip.ptr(efd), _hip.ptr(ead), _hip.ptr(erd), _hip.ptr(etd), stack, _hip.ptr(sl), B,
+    _hip.check(lib.isdqn_replay_gather_rows(_hip.ptr(efd), _hip.ptr(ead), _hip.ptr(erd), _hip.ptr(etd), stack, 0, _hip.ptr(sl), B,
                                             _hip.ptr(ids), _hip.ptr(act), _hip.ptr(rew), _hip.ptr(ter), _hip.stream_ptr()))
     np.testing.assert_array_equal(ids.cpu().numpy(), ef[slots])
     np.testing.assert_array_equal(act.cpu().numpy(), ea[slots])
