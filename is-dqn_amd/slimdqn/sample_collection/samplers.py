@@ -82,7 +82,12 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
     def __init__(self, seed: int, max_capacity: int, priority_exponent: float = 1.0, device: str = "cuda:0") -> None:
         self._max_capacity = max_capacity
         self._priority_exponent = priority_exponent
-        self._sum_tree = sum_tree.SumTree(self._max_capacity, device=device)
+        # The buffer briefly holds max_capacity + 1 keys (add, then evict: replay_buffer.py:190-196), so leaf
+        # `max_capacity` is written.  The reference's tree has that leaf unless max_capacity is a power of two
+        # (then sum_tree.py:33 raises IndexError at the first eviction).  One spare leaf in that case only: the
+        # extra level has a zero right subtree, so every query descends exactly as in the smaller tree.
+        leaves = self._max_capacity + 1 if (self._max_capacity & (self._max_capacity - 1)) == 0 else self._max_capacity
+        self._sum_tree = sum_tree.SumTree(leaves, device=device)
         super().__init__(seed=seed, device=device)
 
     def _transform(self, priority):

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 FEATS = (8, 12, 16, 24)
 
 
-def _agents(K=3, A=5, B=8, T=6, utd=2, lr=1e-3, n=1):
+def _agents(K=3, A=5, B=8, T=6, utd=2, lr=2e-4, n=1):
     from oracle.isdqn import iSDQN as Oracle
     from slimdqn.networks.isdqn import iSDQN
     from tests.gpu_helpers import perturbed_params
@@ -57,13 +57,16 @@ def test_training_run_matches_oracle_agent_and_replay():
     for lh, lo in zip(logs_h, logs_o):
         assert lh.keys() == lo.keys()
         for k in lh:
-            assert abs(lh[k] - lo[k]) < 2e-3 * max(1.0, abs(lo[k])), (k, lh[k], lo[k])
+            # a dozen Adam steps on 8-sample batches: trajectories of two fp32-class implementations drift apart
+            # by a few 1e-3 (Adam normalises near-zero gradients to +-lr); the first log is held to 1e-3
+            tol = 1e-3 if lh is logs_h[0] else 5e-3
+            assert abs(lh[k] - lo[k]) < tol * max(1.0, abs(lo[k])), (k, lh[k], lo[k])
     got = hip.get_model()["params"]
     exp = ora.get_model()["params"]
     for mod in exp:
         for leaf in exp[mod]:
             assert got[mod][leaf].shape == exp[mod][leaf].shape
-            assert np.abs(got[mod][leaf] - exp[mod][leaf]).max() < 2e-3, (mod, leaf)
+            assert np.abs(got[mod][leaf] - exp[mod][leaf]).max() < 1e-3, (mod, leaf)
 
 
 def test_reference_layout_batches_and_functional_signatures():

@@ -104,7 +104,7 @@ def test_sampled_batches_equal_oracle_batches(prioritized):
     from oracle.replay_buffer import ReplayBuffer as ORB, TransitionElement as OT
     from oracle.samplers import PrioritizedSamplingDistribution as OP, UniformSamplingDistribution as OU
 
-    capacity, n = 64, 3
+    capacity, n = 60, 3  # not a power of two: the reference's tree has no leaf `capacity` then (see samplers.py)
     rb = _rb(capacity, n=n, gamma=0.99, seed=7, prioritized=prioritized)
     orb = ORB(OP(7, capacity) if prioritized else OU(7), BATCH, capacity, stack_size=STACK, update_horizon=n, gamma=0.99)
     rng = np.random.default_rng(1)
@@ -132,3 +132,13 @@ def test_sampled_batches_equal_oracle_batches(prioritized):
                 orb.update(keys, priorities=pr)
     if prioritized:
         np.testing.assert_array_equal(rb._sampling_distribution._sum_tree._nodes, orb._sampling_distribution._sum_tree._nodes)
+
+
+def test_power_of_two_capacity_survives_the_first_eviction():
+    """The reference's tree has no leaf `capacity` when capacity is a power of two (IndexError at the first
+    eviction, sum_tree.py:33); the device sampler adds one spare leaf and samples identically otherwise."""
+    rb = _rb(8, prioritized=True, stack=1)
+    for i in range(20):
+        rb.add(_t(np.full(OBS, i, np.uint8), i, 0.0, False, False), priority=1.0 + i)
+    keys = rb._sampling_distribution.sample(64)
+    assert keys.min() >= 20 - 1 - 8 and keys.max() <= 18
