@@ -140,6 +140,22 @@ def cpu_baseline(workload, seconds_budget=20.0):
             "sample": f"{n} steps of the oracle (torch-CPU fp32 restatement) at B={w['B']}, K={w['K']}, replay of {cap} elements, {cores} threads"}
 
 
+def max_over_ranks(seconds, device):
+    """MAX of a scalar over all ranks (identity when torch.distributed is not initialised)."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_value(world, steps, elapsed_max):
+    """Whole-job throughput of `world` independent replicas that each ran `steps` steps."""
+    return world * steps / elapsed_max
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,10 +206,7 @@ def main():
     elapsed = time.perf_counter() - t0
     rep.rb._sampling_distribution._sum_tree.check_status() if w["prioritized"] else None
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max = float(t.item())
+    elapsed_max = max_over_ranks(elapsed, device)
 
     if rank == 0:
         dev_ms = sorted(a.elapsed_time(b) for a, b in ev)
@@ -203,7 +216,7 @@ def main():
         achieved = bytes_step / (dev_ms_avg * 1e-3) / 1e9
         out = {
             "metric": "gradient-steps/sec (batch=256, K=9, 84x84x4)" if args.workload != "c5" else "gradient-steps/sec (batch=1024, K=32, 84x84x4)",
-            "value": world * args.steps / elapsed_max,
+            "value": aggregate_value(world, args.steps, elapsed_max),
             "unit": "gradient-steps/s",
             "n_gpus": world,
             "steps": args.steps,
