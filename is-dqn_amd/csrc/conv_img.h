@@ -1,0 +1,342 @@
+// Image-resident forward convolution for gfx950.
+//
+// The generic engine (gemm_core.h) re-gathers every im2col chunk from global memory in every K step.  A
+// convolution reads each input pixel (k/s)^2 times, and in the iS-DQN torso a whole input image is small
+// (84x84x4 uint8 = 28 KB, 21x21x32 / 11x11x64 fp32 = 56 / 31 KB), so here a workgroup loads the input rows its
+// 128 output pixels need ONCE -- coalesced 16-byte loads of frame rows / channel-last pixels -- converts them
+// to bf16 (hi [+ lo]) and keeps them in LDS with the SAME zero border the SAME padding implies.  The MFMA B
+// fragments of every tap are then plain ds_reads at a per-lane offset into that image; only the weight
+// K-slices stream through the double-buffered LDS stage.  Epilogue: bias + LayerNorm(channels) + ReLU, fused
+// (dqn.py:55-58, 62-65, 69-72), same as ConvFwd.
+//
+//   M = output channels (MT*16 >= cout_p), N = 128 output pixels of ONE image (4 waves x 32), K = taps*cin_p.
+#pragma once
+#include "net_problems.h"
+
+namespace isdqn {
+
+struct ConvImgParams {
+    ConvGeom g;
+    MatSrc W;                // [cout_p][K] fp32
+    const float* in;         // fp32 NHWC input (if !U8)
+    FrameSrc fs;             // uint8 frames (if U8)
+    const float *bias, *gamma, *beta;
+    float scale;
+    float* act;
+    float* z;
+    int n_img, z_img;
+    int tiles_per_img;       // ceil(npix / 128)
+    int R, Wp;               // local rows / padded width of the LDS image
+    int plane_elems;         // bf16 elements of one precision plane of the image
+    int ablate;              // profiling only (env ISDQN_ABLATE): 1 skip fill, 2 skip K loop, 4 skip epilogue, 8 skip weight fetch
+};
+
+template <int MT, int PASSES, bool U8>
+struct ConvImgTraits {
+    static constexpr int BM = MT * 16;
+    static constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
+    static constexpr int B_PLANES = (PASSES >= 3) ? 2 : 1;
+    using GA = TileGeom<BM, false>;
+    static constexpr int A_STAGE = A_PLANES * GA::ELEMS;
+};
+
+template <int MT, int PASSES, bool U8>
+__global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvImgParams p) {
+    using T = ConvImgTraits<MT, PASSES, U8>;
+    using GA = typename T::GA;
+    constexpr int NT = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* a_stage = smem;                              // 2 stages of weight K-slices
+    __bf16* img = smem + 2 * T::A_STAGE;                 // B_PLANES planes of the input tile
+    const ConvGeom& g = p.g;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = (int)blockIdx.x / p.tiles_per_img;
+    const int tile = (int)blockIdx.x - j * p.tiles_per_img;
+    const int p0 = tile * 128;
+    const int oy_min = p0 / g.wout;
+    const int row_base = oy_min * g.stride - g.pad;  // global input row of local row 0
+
+    // ---------------- stage the input rows of this tile into LDS (zero border included) ----------------
+    // FILL_BATCH chunk loads are issued back to back before the first one is consumed: a plain
+    // load -> convert -> store loop is one L2/HBM round trip per iteration.
+    constexpr int FILL_BATCH = 8;
+    if (p.ablate & 1) {
+    } else if constexpr (U8) {
+        // planar: img[c][lr][Wp], chunk = 8 consecutive padded columns
+        const int cpr = p.Wp / 8;                       // chunks per row (Wp is a multiple of 8)
+        const int n_chunks = p.fs.stack * p.R * cpr;
+        int fid[4] = {-1, -1, -1, -1};                  // id-table lookups hoisted out of the fill
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < p.fs.stack) fid[c] = p.fs.frame_id(j, c);
+        for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
+            float v[FILL_BATCH][8];
+            int dst[FILL_BATCH];
+#pragma unroll
+            for (int u = 0; u < FILL_BATCH; ++u) {
+                const int c0 = cb + u * GEMM_THREADS + tid;
+                const bool on = c0 < n_chunks;
+                const int cq = on ? c0 : 0;
+                const int cx = cq % cpr, rest = cq / cpr;
+                const int lr = rest % p.R, c = rest / p.R;
+                int id = c == 0 ? fid[0] : c == 1 ? fid[1] : c == 2 ? fid[2] : fid[3];
+                if (c > 3) id = p.fs.frame_id(j, c);
+                p.fs.patch8_id(on ? id : -1, row_base + lr, cx * 8 - g.pad, v[u]);
+                dst[u] = on ? ((c * p.R + lr) * p.Wp + cx * 8) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < FILL_BATCH; ++u) {
+                bf16x8 hi;
+                round8(v[u], hi);
+                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
+            }
+        }
+    } else {
+        // channel-last: img[lr][xp][cin_p], chunk = 8 channels of one padded pixel
+        const int cpp = g.cin_p / 8;
+        const int n_chunks = p.R * p.Wp * cpp;
+        for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
+            float v[FILL_BATCH][8];
+            int dst[FILL_BATCH];
+#pragma unroll
+            for (int u = 0; u < FILL_BATCH; ++u) {
+                const int c0 = cb + u * GEMM_THREADS + tid;
+                const bool on = c0 < n_chunks;
+                const int cq = on ? c0 : 0;
+                const int cc = cq % cpp, pix = cq / cpp;
+                const int xp = pix % p.Wp, lr = pix / p.Wp;
+                const int iy = row_base + lr, ix = xp - g.pad;
+                const bool ok = on && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+                load8_aligned(p.in + (ok ? (((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + cc * 8 : (int64_t)0), v[u]);
+                mask8(ok, v[u]);
+                dst[u] = on ? (pix * g.cin_p + cc * 8) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < FILL_BATCH; ++u) {
+                bf16x8 hi, lo;
+                if constexpr (PASSES >= 3) {
+                    split8(v[u], hi, lo);
+                    if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + p.plane_elems + dst[u]) = lo;
+                } else {
+                    round8(v[u], hi);
+                }
+                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
+            }
+        }
+    }
+
+    // ---------------- per-lane patch origins of the two 16-pixel column tiles of this wave ----------------
+    int b_org[NT];  // element offset of the patch origin inside one image plane
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int pp = p0 + wave * 32 + nt * 16 + (lane & 15);
+        pp = pp < g.npix ? pp : g.npix - 1;  // lanes past the image compute a duplicate pixel; never stored
+        const int oy = pp / g.wout, ox = pp - oy * g.wout;
+        const int ly0 = oy * g.stride - g.pad - row_base;  // >= 0 by construction
+        const int lx0 = ox * g.stride;                     // padded column of tap kx = 0
+        b_org[nt] = U8 ? (ly0 * p.Wp + lx0) : (ly0 * p.Wp + lx0) * g.cin_p;
+    }
+    const int grp = lane >> 4;
+
+    // ---------------- weight K-slice staging (A operand, ROW image), as in the generic engine ----------------
+    constexpr int A_PER = GA::PER_THREAD;
+    int a_row[A_PER], a_var[A_PER], a_lds[A_PER];
+    bool a_on[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        int c = tid + i * GEMM_THREADS;
+        a_on[i] = c < GA::CHUNKS;
+        if (!a_on[i]) c = 0;
+        a_row[i] = c >> 2;
+        a_var[i] = (c & 3) * 8;
+        a_lds[i] = (c >> 2) * GA::PITCH + (c & 3) * 8;
+    }
+    float sa[A_PER][8];
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) p.W.load(a_row[i], k + a_var[i], sa[i]);
+    };
+    auto stash = [&](int stage) {
+        __bf16* a_hi = a_stage + stage * T::A_STAGE;
+        __bf16* a_lo = a_hi + GA::ELEMS;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            if (!a_on[i]) continue;
+            bf16x8 hi, lo;
+            if constexpr (PASSES >= 2) {
+                split8(sa[i], hi, lo);
+                *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
+            } else {
+                round8(sa[i], hi);
+            }
+            *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (g.K + GEMM_BK - 1) / GEMM_BK;
+    const int k_last = g.K - 8;  // last valid chunk start (weights are zero-filled past K, B only has to stay finite)
+
+    auto compute = [&](int stage, int kk) {
+        const __bf16* a_hi = a_stage + stage * T::A_STAGE;
+        const __bf16* a_lo = a_hi + GA::ELEMS;
+        bf16x8 fa_hi[MT], fa_lo[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            fa_hi[mt] = read_frag<false, GA::PITCH>(a_hi, mt * 16, lane);
+            if constexpr (PASSES >= 2) fa_lo[mt] = read_frag<false, GA::PITCH>(a_lo, mt * 16, lane);
+        }
+        // tap / channel of this lane's 8-element chunk
+        int kq = kk * GEMM_BK + grp * 8;
+        kq = kq < k_last ? kq : k_last;
+        int tap_off;
+        if constexpr (U8) {
+            const int c = kq >> 6, ky = (kq >> 3) & 7;
+            tap_off = (c * p.R + ky) * p.Wp;
+        } else {
+            uint32_t tap, ci, ky, kx;
+            g.d_cinp.divmod((uint32_t)kq, tap, ci);
+            g.d_ksz.divmod(tap, ky, kx);
+            tap_off = ((int)ky * p.Wp + (int)kx) * g.cin_p + (int)ci;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const __bf16* src = img + b_org[nt] + tap_off;
+            bf16x8 fb_hi, fb_lo;
+            if constexpr (U8) {
+                // 8-byte aligned (padded column = 4*ox), two ds_read_b64
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                bf16x4 h0 = *reinterpret_cast<const bf16x4*>(src);
+                bf16x4 h1 = *reinterpret_cast<const bf16x4*>(src + 4);
+                fb_hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+                fb_hi = *reinterpret_cast<const bf16x8*>(src);
+                if constexpr (PASSES >= 3) fb_lo = *reinterpret_cast<const bf16x8*>(src + p.plane_elems);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (PASSES >= 3)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_lo, acc[mt][nt], 0, 0, 0);
+                if constexpr (PASSES >= 2)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[mt], fb_hi, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_hi, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    };
+
+    fetch(0);
+    stash(0);
+    __syncthreads();  // image and first weight slice visible
+    if (!(p.ablate & 2)) {
+        for (int s = 0; s < nsteps; ++s) {
+            const bool more = s + 1 < nsteps && !(p.ablate & 8);
+            if (more) fetch((s + 1) * GEMM_BK);
+            compute(s & 1, s);
+            if (more) stash((s + 1) & 1);
+            __syncthreads();
+        }
+    }
+    if (p.ablate & 4) {
+        if (acc[0][0][0] == 12345.678f) p.act[0] = 1.f;  // keep the accumulators alive
+        return;
+    }
+
+    // ---------------- epilogue: bias + LayerNorm over channels + ReLU (same math as ConvFwd::epilogue) -------------
+    float bi[MT][4], ga[MT][4], be[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int ch = mt * 16 + grp * 4 + r;
+            bool ok = ch < g.cout;
+            bi[mt][r] = ok ? p.bias[ch] : 0.f;
+            ga[mt][r] = (ok && p.gamma) ? p.gamma[ch] : 1.f;
+            be[mt][r] = (ok && p.gamma) ? p.beta[ch] : 0.f;
+        }
+    const float inv_c = 1.0f / (float)g.cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int pp = p0 + wave * 32 + nt * 16 + (lane & 15);
+        float zv[MT][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int ch = mt * 16 + grp * 4 + r;
+                float zz = ch < g.cout ? acc[mt][nt][r] * p.scale + bi[mt][r] : 0.f;
+                zv[mt][r] = zz;
+                s1 += zz;
+                s2 += zz * zz;
+            }
+        float mean = 0.f, rstd = 1.f;
+        if (p.gamma != nullptr) {
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            mean = s1 * inv_c;
+            float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+            rstd = rsqrtf(var + 1e-6f);
+        }
+        if (pp < g.npix) {
+            const int64_t pix = (int64_t)j * g.npix + pp;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                int ch0 = mt * 16 + grp * 4;
+                if (ch0 >= g.cout_p) continue;
+                float4 a, zq;
+                float* ap = &a.x;
+                float* zp = &zq.x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float y = p.gamma != nullptr ? (zv[mt][r] - mean) * (rstd * ga[mt][r]) + be[mt][r] : zv[mt][r];
+                    ap[r] = (ch0 + r < g.cout) ? fmaxf(y, 0.f) : 0.f;
+                    zp[r] = zv[mt][r];
+                }
+                *reinterpret_cast<float4*>(p.act + pix * g.cout_p + ch0) = a;
+                if (j < p.z_img) *reinterpret_cast<float4*>(p.z + pix * g.cout_p + ch0) = zq;
+            }
+        }
+    }
+}
+
+template <int MT, int PASSES, bool U8>
+static int launch_conv_fwd_img(const ConvImgParams& p, hipStream_t st) {
+    using T = ConvImgTraits<MT, PASSES, U8>;
+    const int lds = (2 * T::A_STAGE + T::B_PLANES * p.plane_elems) * 2;
+    static int configured_for = 0;
+    if (lds > 65536 && lds > configured_for) {
+        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_img_kernel<MT, PASSES, U8>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured_for = lds;
+    }
+    hipLaunchKernelGGL((conv_fwd_img_kernel<MT, PASSES, U8>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS), lds,
+                       st, p);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
+// LDS bytes the image-resident kernel would need for this layer (host-side feasibility check)
+static inline int conv_img_geometry(const ConvGeom& g, bool u8, int stack, int b_planes, int mt, int a_planes, int& R,
+                                    int& Wp, int& plane_elems) {
+    int rows_per_tile = g.npix <= 128 ? g.hout : ((128 + g.wout - 2) / g.wout + 1);
+    if (rows_per_tile > g.hout) rows_per_tile = g.hout;
+    R = g.stride * (rows_per_tile - 1) + g.ksz;
+    if (u8) {
+        Wp = ((g.wout - 1) * g.stride + g.ksz + 7) / 8 * 8;  // padded width, room for the right-most patch
+        plane_elems = stack * R * Wp;
+    } else {
+        Wp = (g.wout - 1) * g.stride + g.ksz;           // = win + pad_lo + pad_hi
+        plane_elems = R * Wp * g.cin_p;
+    }
+    const int a_stage = a_planes * (mt * 16) * (GEMM_BK + 8);
+    return (2 * a_stage + b_planes * plane_elems) * 2;
+}
+
+}  // namespace isdqn

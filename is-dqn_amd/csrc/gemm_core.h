@@ -162,10 +162,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
     auto fetch = [&](int k) {
 #pragma unroll
         for (int i = 0; i < GA::PER_THREAD; ++i)
-            if (a_on[i]) p.load_a(tile, actx[i], k + a_var[i], sa[i]);
+            if (GA::CHUNKS % GEMM_THREADS == 0 || a_on[i]) p.load_a(tile, actx[i], k + a_var[i], sa[i]);
 #pragma unroll
         for (int i = 0; i < GB::PER_THREAD; ++i)
-            if (b_on[i]) p.load_b(tile, bctx[i], k + b_var[i], sb[i]);
+            if (GB::CHUNKS % GEMM_THREADS == 0 || b_on[i]) p.load_b(tile, bctx[i], k + b_var[i], sb[i]);
     };
     auto stash = [&](int stage) {
         __bf16* base = smem + stage * T::STAGE_ELEMS;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
         __bf16* b_lo = b_hi + GB::ELEMS;
 #pragma unroll
         for (int i = 0; i < GA::PER_THREAD; ++i) {
-            if (!a_on[i]) continue;
+            if (GA::CHUNKS % GEMM_THREADS != 0 && !a_on[i]) continue;
             bf16x8 hi, lo;
             if constexpr (PASSES >= 2) {
                 split8(sa[i], hi, lo);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
         }
 #pragma unroll
         for (int i = 0; i < GB::PER_THREAD; ++i) {
-            if (!b_on[i]) continue;
+            if (GB::CHUNKS % GEMM_THREADS != 0 && !b_on[i]) continue;
             bf16x8 hi, lo;
             if constexpr (PASSES >= 3) {
                 split8(sb[i], hi, lo);
@@ -273,6 +273,13 @@ __device__ __forceinline__ void zero8(float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = 0.f;
 }
+// Loaders are BRANCH-FREE: the address is clamped to a valid one, the load is unconditional and the result
+// is selected afterwards.  A load inside a divergent `if` makes hipcc branch around it and wait for it
+// (s_waitcnt at the join), which serialises every chunk of a K step into its own L2 round trip.
+__device__ __forceinline__ void mask8(bool ok, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = ok ? v[i] : 0.f;
+}
 __device__ __forceinline__ void load8_aligned(const float* p, float (&v)[8]) {
     float4 a = *reinterpret_cast<const float4*>(p);
     float4 b = *reinterpret_cast<const float4*>(p + 4);
@@ -288,17 +295,21 @@ struct MatSrc {
     const float* base;
     int ld, outer, inner;
     int aligned8;
+    // ALIGNED is a compile-time choice: a runtime flag keeps both bodies (and their waits) in the K loop
+    template <bool ALIGNED = true>
     __device__ __forceinline__ void load(int o, int i0, float (&v)[8]) const {
-        if (o >= outer || i0 >= inner) {
-            zero8(v);
-            return;
-        }
-        const float* p = base + (int64_t)o * ld + i0;
-        if (aligned8) {
+        const bool ok = (o < outer) && (i0 < inner);
+        const float* p = base + (ok ? (int64_t)o * ld + i0 : (int64_t)0);
+        if constexpr (ALIGNED) {
             load8_aligned(p, v);
+            mask8(ok, v);
         } else {
+            const int last = ok ? inner - 1 - i0 : 0;  // last valid element offset in this chunk
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (i0 + j < inner) ? p[j] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                float x = p[j <= last ? j : last];
+                v[j] = (ok && j <= last) ? x : 0.f;
+            }
         }
     }
 };

@@ -3,7 +3,9 @@
 // slimdqn/networks/isdqn.py:82-135.  Contractions run on the MFMA tile engine (gemm_core.h,
 // net_problems.h); the row-wise kernels below are the HBM-bound remainder.
 #include <stdarg.h>
+#include <stdlib.h>
 
+#include "conv_img.h"
 #include "net_plan.h"
 #include "net_problems.h"
 
@@ -390,8 +392,17 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* _
     const float c1 = consts[0], c2 = consts[1];  // 1 - b1^t, 1 - b2^t (loss_finalize_kernel)
     int64_t i = ((int64_t)(blockIdx.x - en.block_start) * 256 + threadIdx.x) * 4;
     if (i >= en.size) return;
-    float4 g = *reinterpret_cast<const float4*>(en.g + i);
-    for (int s = 1; s < en.n_slabs; ++s) {
+    // slab reduction, 8 independent loads in flight per round (fixed order: deterministic)
+    float4 g = float4{0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= en.n_slabs; s += 8) {
+        float4 h[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) h[u] = *reinterpret_cast<const float4*>(en.g + (int64_t)(s + u) * en.slab_stride + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { g.x += h[u].x; g.y += h[u].y; g.z += h[u].z; g.w += h[u].w; }
+    }
+    for (; s < en.n_slabs; ++s) {
         float4 h = *reinterpret_cast<const float4*>(en.g + (int64_t)s * en.slab_stride + i);
         g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
     }
@@ -470,8 +481,44 @@ static int launch_conv_fwd(const Layer& l, const float* params, const NetInput& 
     return launch_gemm(p, ceil_div(p.n_pix_total, 128), st);
 }
 
+// image-resident forward convolution (conv_img.h) when the input tile fits in LDS; generic engine otherwise
+static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int n_img,
+                        int z_img, float* act, float* z, hipStream_t st, bool* done) {
+    *done = false;
+    ConvImgParams ip;
+    ip.g = conv_geom(l);
+    const int mt = l.cout_p <= 32 ? 2 : 4;
+    const int passes = x3 ? (l.is_u8 ? 2 : 3) : 1;
+    const int lds = conv_img_geometry(ip.g, l.is_u8, l.cin, passes >= 3 ? 2 : 1, mt, passes >= 2 ? 2 : 1, ip.R, ip.Wp,
+                                      ip.plane_elems);
+    if (lds > 150 * 1024 || (l.is_u8 && l.win < 8)) return ISDQN_OK;
+    ip.W = MatSrc{params + l.w_off, l.K, l.cout_p, l.K, 1};
+    ip.in = act_in;
+    ip.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win};
+    ip.bias = params + l.b_off;
+    ip.gamma = l.has_ln ? params + l.g_off : nullptr;
+    ip.beta = l.has_ln ? params + l.be_off : nullptr;
+    ip.scale = l.is_u8 ? (1.0f / 255.0f) : 1.0f;
+    ip.act = act; ip.z = z; ip.n_img = n_img; ip.z_img = z_img;
+    ip.tiles_per_img = ceil_div(l.npix, 128);
+    {
+        const char* e = getenv("ISDQN_ABLATE");
+        ip.ablate = e ? atoi(e) : 0;
+    }
+    *done = true;
+    if (l.is_u8) {
+        if (passes == 2) return mt == 2 ? launch_conv_fwd_img<2, 2, true>(ip, st) : launch_conv_fwd_img<4, 2, true>(ip, st);
+        return mt == 2 ? launch_conv_fwd_img<2, 1, true>(ip, st) : launch_conv_fwd_img<4, 1, true>(ip, st);
+    }
+    if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false>(ip, st) : launch_conv_fwd_img<4, 3, false>(ip, st);
+    return mt == 2 ? launch_conv_fwd_img<2, 1, false>(ip, st) : launch_conv_fwd_img<4, 1, false>(ip, st);
+}
+
 static int conv_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int n_img,
                     int z_img, float* act, float* z, hipStream_t st) {
+    bool done = false;
+    int rc = conv_fwd_img(l, x3, params, in, act_in, n_img, z_img, act, z, st, &done);
+    if (rc || done) return rc;
     const bool small = l.cout_p <= 32;
     if (l.is_u8) {
         if (x3) return small ? launch_conv_fwd<32, 2, true>(l, params, in, act_in, n_img, z_img, act, z, st)
@@ -486,10 +533,12 @@ static int conv_fwd(const Layer& l, bool x3, const float* params, const NetInput
 }
 
 // C[split][M][N] = A . B^T over row-major sources.  a_tr/b_tr: the operand is stored [K][rows].
-template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, int PASSES>
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, int PASSES, bool AL, bool A2PART, bool ADAM = false>
 static int launch_plain(const MatSrc& A, const float* A2, int a_split, const MatSrc& B, float* C, int ldc, int M,
-                        int N, int K, int splits, int64_t slab_stride, hipStream_t st) {
-    PlainGemm<BM, BN, WM, WN, ATR, BTR, PASSES> p;
+                        int N, int K, int splits, int64_t slab_stride, hipStream_t st,
+                        const AdamFuse* adam = nullptr) {
+    PlainGemm<BM, BN, WM, WN, ATR, BTR, PASSES, AL, A2PART, ADAM> p;
+    if (adam) p.adam = *adam;
     p.A = A; p.B = B; p.A2 = A2; p.a_split = a_split; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
     p.tiles_m = ceil_div(M, BM); p.tiles_n = ceil_div(N, BN);
     int ksteps = ceil_div(K, GEMM_BK);
@@ -509,11 +558,14 @@ static int effective_splits(int K, int splits) {
     return ceil_div(ksteps, sps);
 }
 
-template <bool ATR, bool BTR>
+template <bool ATR, bool BTR, bool AL = true, bool A2PART = false>
 static int plain_big(bool x3, const MatSrc& A, const float* A2, int a_split, const MatSrc& B, float* C, int ldc,
                      int M, int N, int K, int splits, int64_t slab_stride, hipStream_t st) {
-    if (x3) return launch_plain<128, 128, 2, 2, ATR, BTR, 3>(A, A2, a_split, B, C, ldc, M, N, K, splits, slab_stride, st);
-    return launch_plain<128, 128, 2, 2, ATR, BTR, 1>(A, A2, a_split, B, C, ldc, M, N, K, splits, slab_stride, st);
+    if (x3)
+        return launch_plain<128, 128, 2, 2, ATR, BTR, 3, AL, A2PART>(A, A2, a_split, B, C, ldc, M, N, K, splits,
+                                                                     slab_stride, st);
+    return launch_plain<128, 128, 2, 2, ATR, BTR, 1, AL, A2PART>(A, A2, a_split, B, C, ldc, M, N, K, splits, slab_stride,
+                                                                 st);
 }
 
 static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int rows,
@@ -529,10 +581,21 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInpu
     }
     B = MatSrc{params + l.w_off, l.in_p, l.out_f, l.in_p, 1};
     const int64_t slab_stride = (int64_t)rows * l.out_p;
-    int rc = plain_big<false, false>(x3, A, A2, a_split, B, slab, l.out_p, rows, l.out_f, l.K, l.fwd_splits,
-                                     slab_stride, st);
+    int rc;
+    if (l.in_unpadded_ld) {
+        // caller-provided observations: no alignment promise; MatSrc bounds use the true widths
+        MatSrc Bu = B;
+        Bu.inner = l.in_f;
+        rc = A2 ? plain_big<false, false, false, true>(x3, A, A2, a_split, Bu, slab, l.out_p, rows, l.out_f, l.in_f,
+                                                       l.fwd_splits, slab_stride, st)
+                : plain_big<false, false, false, false>(x3, A, nullptr, 0, Bu, slab, l.out_p, rows, l.out_f, l.in_f,
+                                                        l.fwd_splits, slab_stride, st);
+    } else {
+        rc = plain_big<false, false>(x3, A, nullptr, 0, B, slab, l.out_p, rows, l.out_f, l.K, l.fwd_splits, slab_stride,
+                                     st);
+    }
     if (rc) return rc;
-    int ns = effective_splits(l.K, l.fwd_splits);
+    int ns = effective_splits(l.in_unpadded_ld ? l.in_f : l.K, l.fwd_splits);
     hipLaunchKernelGGL(dense_post_kernel, dim3(rows), dim3(256), l.out_p * sizeof(float), st, slab, ns, slab_stride,
                        rows, l.out_f, l.out_p, params + l.b_off, l.has_ln ? params + l.g_off : nullptr,
                        l.has_ln ? params + l.be_off : nullptr, l.has_relu, act, z, z_rows);
@@ -805,26 +868,8 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         } else {
             add_entry(l.b_off, l.out_p, ws + P.dbh_off, 1, 0);
         }
-        // weight gradient -> slabs
-        int w_slabs;
-        if (l.kind == 0) {
-            if (l.is_u8) rc = x3 ? launch_conv_wgrad<2, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, st)
-                                 : launch_conv_wgrad<1, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, st);
-            else rc = x3 ? launch_conv_wgrad<3, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, st)
-                         : launch_conv_wgrad<1, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, st);
-            w_slabs = conv_wgrad_slabs(l, B);
-        } else {
-            // dW[out][in_p] = sum_b dz[b][out] * a[b][in_p] : both operands stored [K = b][rows]
-            MatSrc A{dz_cur, dz_ld, B, l.out_p, 1};
-            MatSrc Bm = l.in_unpadded_ld ? MatSrc{in.obs, l.in_unpadded_ld, B, l.in_f, 0}
-                                         : MatSrc{act_in, l.in_p, B, l.in_p, 1};
-            rc = plain_big<true, true>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B, l.gw_slabs,
-                                       l.w_size, st);
-            w_slabs = effective_splits(B, l.gw_slabs);
-        }
-        if (rc) return rc;
-        add_entry(l.w_off, l.w_size, ws + l.gw_off, w_slabs, l.w_size);
-        // data gradient for the layer below
+        // data gradient for the layer below first: it reads this layer's weights, which the fused-Adam
+        // weight-gradient epilogue below updates in place
         if (i > 0) {
             if (l.kind == 0) {
                 const bool small = l.cin_p <= 32;
@@ -840,6 +885,40 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
             }
             if (rc) return rc;
         }
+        // weight gradient -> slabs (or straight into Adam when one workgroup holds the whole contraction)
+        int w_slabs;
+        bool fused_adam = false;
+        if (l.kind == 0) {
+            if (l.is_u8) rc = x3 ? launch_conv_wgrad<2, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, st)
+                                 : launch_conv_wgrad<1, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, st);
+            else rc = x3 ? launch_conv_wgrad<3, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, st)
+                         : launch_conv_wgrad<1, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, st);
+            w_slabs = conv_wgrad_slabs(l, B);
+        } else {
+            // dW[out][in_p] = sum_b dz[b][out] * a[b][in_p] : both operands stored [K = b][rows]
+            MatSrc A{dz_cur, dz_ld, B, l.out_p, 1};
+            MatSrc Bm = l.in_unpadded_ld ? MatSrc{in.obs, l.in_unpadded_ld, B, l.in_f, 0}
+                                         : MatSrc{act_in, l.in_p, B, l.in_p, 1};
+            w_slabs = effective_splits(B, l.gw_slabs);
+            if (w_slabs == 1 && !l.in_unpadded_ld) {
+                fused_adam = true;
+                AdamFuse af{params + l.w_off, adam_m + l.w_off, adam_v + l.w_off, ws + P.adam_tab_off,
+                            cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps,
+                            grad_out ? grad_out + l.w_off : nullptr};
+                rc = x3 ? launch_plain<128, 128, 2, 2, true, true, 3, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                         l.out_p, l.in_p, B, 1, 0, st, &af)
+                        : launch_plain<128, 128, 2, 2, true, true, 1, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                         l.out_p, l.in_p, B, 1, 0, st, &af);
+            } else {
+                rc = l.in_unpadded_ld
+                         ? plain_big<true, true, false>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
+                                                        l.gw_slabs, l.w_size, st)
+                         : plain_big<true, true>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
+                                                 l.gw_slabs, l.w_size, st);
+            }
+        }
+        if (rc) return rc;
+        if (!fused_adam) add_entry(l.w_off, l.w_size, ws + l.gw_off, w_slabs, l.w_size);
     }
     tab.total_blocks = blocks;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, tab, params, adam_m, adam_v, ws + P.adam_tab_off,
@@ -913,8 +992,8 @@ extern "C" int isdqn_selftest_gemm(const float* A, const float* B, float* C, int
     MatSrc a = a_tr ? MatSrc{A, M, K, M, 0} : MatSrc{A, K, M, K, 0};
     MatSrc b = b_tr ? MatSrc{B, N, K, N, 0} : MatSrc{B, K, N, K, 0};
     const int64_t slab = (int64_t)M * N;
-    if (!a_tr && !b_tr) return plain_big<false, false>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
-    if (!a_tr && b_tr) return plain_big<false, true>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
-    if (a_tr && !b_tr) return plain_big<true, false>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
-    return plain_big<true, true>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
+    if (!a_tr && !b_tr) return plain_big<false, false, false>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
+    if (!a_tr && b_tr) return plain_big<false, true, false>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
+    if (a_tr && !b_tr) return plain_big<true, false, false>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
+    return plain_big<true, true, false>(x3, a, nullptr, 0, b, C, N, M, N, K, split_k, slab, st);
 }

@@ -30,28 +30,26 @@ struct FrameSrc {
         }
         return ids[(int64_t)j * stack + c];
     }
-    // 8 horizontally adjacent pixels (ix0 .. ix0+7) of row iy, zero outside the frame; exact in bf16
+    // 8 horizontally adjacent pixels (ix0 .. ix0+7) of row iy of frame `id`, zero outside the frame; exact in
+    // bf16.  Branch-free: one unaligned 8-byte load from a clamped position, then a 64-bit shift moves the
+    // bytes into place and shifts zeros in for the columns that fall outside the row (needs W >= 8).
+    __device__ __forceinline__ void patch8_id(int id, int iy, int ix0, float (&v)[8]) const {
+        const bool ok = (id >= 0) && (iy >= 0) && (iy < H) && (ix0 > -8) && (ix0 < W);
+        const int ixc = min(max(ix0, 0), W - 8);
+        const uint8_t* row = frames + (ok ? (int64_t)id * stride + (int64_t)iy * W + ixc : (int64_t)0);
+        unsigned long long u;
+        __builtin_memcpy(&u, row, 8);  // one (unaligned) global_load_dwordx2
+        const int d = ix0 - ixc;       // < 0: left border, > 0: right border
+        u = d >= 0 ? (u >> (8 * d)) : (u << (8 * (-d)));
+        u = ok ? u : 0ull;
+        const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+        v[0] = (float)(lo & 0xff); v[1] = (float)((lo >> 8) & 0xff);
+        v[2] = (float)((lo >> 16) & 0xff); v[3] = (float)(lo >> 24);
+        v[4] = (float)(hi & 0xff); v[5] = (float)((hi >> 8) & 0xff);
+        v[6] = (float)((hi >> 16) & 0xff); v[7] = (float)(hi >> 24);
+    }
     __device__ __forceinline__ void patch8(int j, int c, int iy, int ix0, float (&v)[8]) const {
-        int id = frame_id(j, c);
-        if (id < 0 || iy < 0 || iy >= H) {
-            zero8(v);
-            return;
-        }
-        const uint8_t* row = frames + (int64_t)id * stride + (int64_t)iy * W;
-        if (ix0 >= 0 && ix0 + 8 <= W) {
-            uint2 u;
-            __builtin_memcpy(&u, row + ix0, 8);  // one (unaligned) global_load_dwordx2
-            v[0] = (float)(u.x & 0xff); v[1] = (float)((u.x >> 8) & 0xff);
-            v[2] = (float)((u.x >> 16) & 0xff); v[3] = (float)(u.x >> 24);
-            v[4] = (float)(u.y & 0xff); v[5] = (float)((u.y >> 8) & 0xff);
-            v[6] = (float)((u.y >> 16) & 0xff); v[7] = (float)(u.y >> 24);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int ix = ix0 + i;
-                v[i] = (ix >= 0 && ix < W) ? (float)row[ix] : 0.f;
-            }
-        }
+        patch8_id(frame_id(j, c), iy, ix0, v);
     }
 };
 
@@ -59,7 +57,19 @@ struct FrameSrc {
 // Plain GEMM over row-major matrices (dense forward / data-grad / weight-grad, head, self-test)
 //   C[split][m][n] = sum_{k in split} A(m,k) * B(n,k)
 // ---------------------------------------------------------------------------------------------
-template <int BM_, int BN_, int WM_, int WN_, bool ATR, bool BTR, int PASSES_>
+// AL: both sources promise 16-B aligned, 8-element-granular rows (everything except caller-provided fc
+// observations and the self-test); A2: operand A comes in two row blocks (fc: state / next_state).
+// Adam applied in the epilogue (optax.adam, isdqn.py:46, 85-86): used by weight-gradient GEMMs whose tile holds
+// the complete gradient (no split-K), so the gradient of the big dense kernel is never written to HBM.
+struct AdamFuse {
+    float *p, *m, *v;        // parameter tensor and its moments, same [M][ldc] layout as C
+    const float* consts;     // {1 - b1^t, 1 - b2^t}
+    float lr, b1, b2, eps;
+    float* grad_out;         // optional: also store the raw gradient (tests)
+};
+
+template <int BM_, int BN_, int WM_, int WN_, bool ATR, bool BTR, int PASSES_, bool AL = true, bool A2PART = false,
+          bool ADAM = false>
 struct PlainGemm {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, PASSES = PASSES_;
     static constexpr bool A_TR = ATR, B_TR = BTR;
@@ -70,6 +80,7 @@ struct PlainGemm {
     int ldc, M, N, K;
     int tiles_m, tiles_n, splits, steps_per_split;
     int64_t slab_stride;
+    AdamFuse adam;
     struct Tile { int m0, n0, k0, k1, split; };
     struct ACtx { int fixed; };
     struct BCtx { int fixed; };
@@ -88,26 +99,48 @@ struct PlainGemm {
     __device__ __forceinline__ BCtx b_ctx(const Tile&, int fixed) const { return BCtx{fixed}; }
     __device__ __forceinline__ void load_a(const Tile&, const ACtx& c, int var, float (&v)[8]) const {
         if constexpr (!ATR) {
-            if (A2 != nullptr && c.fixed >= a_split) {
+            if constexpr (A2PART) {
+                const bool second = c.fixed >= a_split;
                 MatSrc s = A;
-                s.base = A2;
-                s.outer = A.outer - a_split;
-                s.load(c.fixed - a_split, var, v);
+                s.base = second ? A2 : A.base;
+                s.load<AL>(second ? c.fixed - a_split : c.fixed, var, v);
             } else {
-                MatSrc s = A;
-                if (A2 != nullptr) s.outer = a_split;
-                s.load(c.fixed, var, v);
+                A.load<AL>(c.fixed, var, v);
             }
         } else {
-            A.load(var, c.fixed, v);
+            A.load<AL>(var, c.fixed, v);
         }
     }
     __device__ __forceinline__ void load_b(const Tile&, const BCtx& c, int var, float (&v)[8]) const {
-        if constexpr (!BTR) B.load(c.fixed, var, v);
-        else B.load(var, c.fixed, v);
+        if constexpr (!BTR) B.load<AL>(c.fixed, var, v);
+        else B.load<AL>(var, c.fixed, v);
     }
     template <int MT, int NT>
     __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const {
+        if constexpr (ADAM) {
+            const float c1 = adam.consts[0], c2 = adam.consts[1];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    int col = n_wave + nt * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = m_wave + mt * 16 + (lane >> 4) * 4 + r;
+                        if (row < M && col < N) {
+                            const int64_t i = (int64_t)row * ldc + col;
+                            const float g = acc[mt][nt][r];
+                            if (adam.grad_out) adam.grad_out[i] = g;
+                            const float mm = adam.b1 * adam.m[i] + (1.f - adam.b1) * g;
+                            const float vv = adam.b2 * adam.v[i] + (1.f - adam.b2) * g * g;
+                            adam.m[i] = mm;
+                            adam.v[i] = vv;
+                            adam.p[i] = adam.p[i] - adam.lr * ((mm / c1) / (sqrtf(vv / c2) + adam.eps));
+                        }
+                    }
+                }
+            return;
+        }
         float* c = C + (int64_t)t.split * slab_stride;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -148,7 +181,7 @@ struct ConvFwd {
     int n_pix_total, z_pix;
     struct Tile { int m0, n0, k0, k1; };
     struct ACtx { int row; };
-    struct BCtx { int j, iy0, ix0, valid; };
+    struct BCtx { int j, iy0, ix0, valid, f0, f1, f2, f3; };
     __device__ __forceinline__ bool tile(int bid, Tile& t) const {
         t.m0 = 0; t.n0 = bid * BN; t.k0 = 0; t.k1 = g.K;
         return t.n0 < n_pix_total;
@@ -164,19 +197,31 @@ struct ConvFwd {
         c.j = (int)j;
         c.iy0 = (int)oy * g.stride - g.pad;
         c.ix0 = (int)ox * g.stride - g.pad;
+        c.f0 = c.f1 = c.f2 = c.f3 = -1;
+        if constexpr (U8) {  // the id-table lookup is hoisted out of the K loop (it would be a dependent load per chunk)
+            c.f0 = fs.frame_id(c.j, 0);
+            if (fs.stack > 1) c.f1 = fs.frame_id(c.j, 1);
+            if (fs.stack > 2) c.f2 = fs.frame_id(c.j, 2);
+            if (fs.stack > 3) c.f3 = fs.frame_id(c.j, 3);
+        }
         return c;
     }
     __device__ __forceinline__ void load_b(const Tile&, const BCtx& c, int k, float (&v)[8]) const {
-        if (!c.valid || k >= g.K) { zero8(v); return; }
+        const bool kok = c.valid && (k < g.K);
         if constexpr (U8) {
-            fs.patch8(c.j, k >> 6, c.iy0 + ((k >> 3) & 7), c.ix0, v);
+            const int plane = k >> 6;
+            int id = plane == 0 ? c.f0 : plane == 1 ? c.f1 : plane == 2 ? c.f2 : c.f3;
+            if (plane > 3) id = fs.frame_id(c.j, kok ? plane : 0);  // stacks deeper than 4: wave-uniform slow path
+            fs.patch8_id(kok ? id : -1, c.iy0 + ((k >> 3) & 7), c.ix0, v);
         } else {
             uint32_t tap, ci, ky, kx;
-            g.d_cinp.divmod(k, tap, ci);
+            g.d_cinp.divmod(kok ? k : 0, tap, ci);
             g.d_ksz.divmod(tap, ky, kx);
-            int iy = c.iy0 + (int)ky, ix = c.ix0 + (int)kx;
-            if (iy < 0 || iy >= g.hin || ix < 0 || ix >= g.win) { zero8(v); return; }
-            load8_aligned(in + (((int64_t)c.j * g.hin + iy) * g.win + ix) * g.cin_p + ci, v);
+            const int iy = c.iy0 + (int)ky, ix = c.ix0 + (int)kx;
+            const bool ok = kok && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+            const float* p = in + (ok ? (((int64_t)c.j * g.hin + iy) * g.win + ix) * g.cin_p + ci : (int64_t)0);
+            load8_aligned(p, v);
+            mask8(ok, v);
         }
     }
     template <int MT, int NT>
@@ -276,12 +321,13 @@ struct ConvDgrad {
     }
     __device__ __forceinline__ ACtx a_ctx(const Tile&, int ci0) const { return ACtx{ci0}; }
     __device__ __forceinline__ void load_a(const Tile& t, const ACtx& c, int k, float (&v)[8]) const {
-        if (k >= Kc || c.ci0 >= g.cin_p) { zero8(v); return; }
+        const bool ok = (k < Kc) && (c.ci0 < g.cin_p);
         uint32_t jt, co;
-        g.d_coutp.divmod(k, jt, co);
+        g.d_coutp.divmod(ok ? k : 0, jt, co);
         int jy = (int)jt / T, jx = (int)jt % T;
         int ky = t.py + g.stride * jy, kx = t.px + g.stride * jx;
-        load8_aligned(W + (int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + c.ci0, v);
+        load8_aligned(W + (ok ? (int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + c.ci0 : (int64_t)0), v);
+        mask8(ok, v);
     }
     __device__ __forceinline__ void decode(const Tile& t, int q, int& j, int& iy, int& ix) const {
         uint32_t jj, rem, a, b;
@@ -299,13 +345,14 @@ struct ConvDgrad {
         return c;
     }
     __device__ __forceinline__ void load_b(const Tile&, const BCtx& c, int k, float (&v)[8]) const {
-        if (!c.valid || k >= Kc) { zero8(v); return; }
+        const bool kok = c.valid && (k < Kc);
         uint32_t jt, co;
-        g.d_coutp.divmod(k, jt, co);
+        g.d_coutp.divmod(kok ? k : 0, jt, co);
         int jy = (int)jt / T, jx = (int)jt % T;
         int oy = c.oyb - jy, ox = c.oxb - jx;
-        if (oy < 0 || oy >= g.hout || ox < 0 || ox >= g.wout) { zero8(v); return; }
-        load8_aligned(dz + (((int64_t)c.j * g.hout + oy) * g.wout + ox) * g.cout_p + co, v);
+        const bool ok = kok && oy >= 0 && oy < g.hout && ox >= 0 && ox < g.wout;
+        load8_aligned(dz + (ok ? (((int64_t)c.j * g.hout + oy) * g.wout + ox) * g.cout_p + co : (int64_t)0), v);
+        mask8(ok, v);
     }
     template <int MT, int NT>
     __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const {
@@ -368,17 +415,19 @@ struct ConvWgrad {
         return c;
     }
     __device__ __forceinline__ void load_b(const Tile&, const BCtx& c, int pix, float (&v)[8]) const {
-        if (!c.valid || pix >= n_pix) { zero8(v); return; }
+        const bool pok = c.valid && (pix < n_pix);
         uint32_t j, p, oy, ox;
-        g.d_npix.divmod(pix, j, p);
+        g.d_npix.divmod(pok ? pix : 0, j, p);
         g.d_wout.divmod(p, oy, ox);
         int iy = (int)oy * g.stride - g.pad + c.ky;
         int ix = (int)ox * g.stride - g.pad + c.kx;
         if constexpr (U8) {
-            fs.patch8((int)j, c.c_or_ci, iy, ix, v);
+            int id = fs.frame_id((int)j, c.c_or_ci);
+            fs.patch8_id(pok ? id : -1, iy, ix, v);
         } else {
-            if (iy < 0 || iy >= g.hin || ix < 0 || ix >= g.win) { zero8(v); return; }
-            load8_aligned(in + (((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + c.c_or_ci, v);
+            const bool ok = pok && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+            load8_aligned(in + (ok ? (((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + c.c_or_ci : (int64_t)0), v);
+            mask8(ok, v);
         }
     }
     template <int MT, int NT>
