@@ -339,4 +339,247 @@ static inline int conv_img_geometry(const ConvGeom& g, bool u8, int stack, int b
     return (2 * a_stage + b_planes * plane_elems) * 2;
 }
 
+
+// =====================================================================================================
+// Image-resident weight gradient
+// =====================================================================================================
+//   dW[co][k'] = sum_images sum_pix dz[pix][co] * in[pix shifted by the tap of k'][ci of k']
+// A workgroup owns a group of images and a slice of the k' columns (a few taps).  Per image it stages the
+// dz image ([pix][cout_p]) and the input image (zero-bordered, as in the forward kernel) in LDS once; the
+// contraction index (pixels) is the slow index of BOTH images, so every MFMA fragment is a transposing
+// ds_read_b64_tr_b16 at a per-lane pixel address -- no im2col gather from HBM, and the dz fragments of a
+// K step are reused by all taps.  Accumulators stay in registers across the images of the group; one fp32
+// slab per image group goes to HBM (reduced by the Adam kernel).
+struct ConvWgradImgParams {
+    ConvGeom g;
+    const float* dz;     // [n_img][npix][cout_p]
+    const float* in;     // fp32 NHWC input (if !U8)
+    FrameSrc fs;         // uint8 frames (if U8)
+    float* slabs;        // [n_img_groups][cout_p][K]
+    float scale;
+    int n_img, G;        // images per workgroup
+    int n_col_groups, NC;  // k' columns per workgroup (multiple of 64)
+    int R, Wp;           // input image: local rows (whole image), padded width
+    int in_plane;        // elements of one precision plane of the input image
+    int PA, npix_pad;    // dz image: row pitch (elements), rows padded to a multiple of 32
+    int dz_plane;        // elements of one precision plane of the dz image
+};
+
+template <bool U8, int PASSES>
+__device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, const ConvGeom& g, const FrameSrc& fs,
+                                                 const float* in, int j, int row_base, int R, int Wp, int tid) {
+    constexpr int FILL_BATCH = 8;
+    if constexpr (U8) {
+        const int cpr = Wp / 8;
+        const int n_chunks = fs.stack * R * cpr;
+        int fid[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < fs.stack) fid[c] = fs.frame_id(j, c);
+        for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
+            float v[FILL_BATCH][8];
+            int dst[FILL_BATCH];
+#pragma unroll
+            for (int u = 0; u < FILL_BATCH; ++u) {
+                const int c0 = cb + u * GEMM_THREADS + tid;
+                const bool on = c0 < n_chunks;
+                const int cq = on ? c0 : 0;
+                const int cx = cq % cpr, rest = cq / cpr;
+                const int lr = rest % R, c = rest / R;
+                int id = c == 0 ? fid[0] : c == 1 ? fid[1] : c == 2 ? fid[2] : fid[3];
+                if (c > 3) id = fs.frame_id(j, c);
+                fs.patch8_id(on ? id : -1, row_base + lr, cx * 8 - g.pad, v[u]);
+                dst[u] = on ? ((c * R + lr) * Wp + cx * 8) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < FILL_BATCH; ++u) {
+                bf16x8 hi;
+                round8(v[u], hi);
+                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
+            }
+        }
+    } else {
+        const int cpp = g.cin_p / 8;
+        const int n_chunks = R * Wp * cpp;
+        for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
+            float v[FILL_BATCH][8];
+            int dst[FILL_BATCH];
+#pragma unroll
+            for (int u = 0; u < FILL_BATCH; ++u) {
+                const int c0 = cb + u * GEMM_THREADS + tid;
+                const bool on = c0 < n_chunks;
+                const int cq = on ? c0 : 0;
+                const int cc = cq % cpp, pix = cq / cpp;
+                const int xp = pix % Wp, lr = pix / Wp;
+                const int iy = row_base + lr, ix = xp - g.pad;
+                const bool ok = on && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+                load8_aligned(in + (ok ? (((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + cc * 8 : (int64_t)0), v[u]);
+                mask8(ok, v[u]);
+                dst[u] = on ? (pix * g.cin_p + cc * 8) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < FILL_BATCH; ++u) {
+                bf16x8 hi, lo;
+                if constexpr (PASSES >= 3) {
+                    split8(v[u], hi, lo);
+                    if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + plane_elems + dst[u]) = lo;
+                } else {
+                    round8(v[u], hi);
+                }
+                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
+            }
+        }
+    }
+}
+
+// one transposed fragment: 8 k-rows given by two per-lane row addresses (rows q and q+4 of the lane's 8-row group)
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* a0, const __bf16* a1) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)a1);
+    s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int MT, int NTW, int PASSES, bool U8>
+__global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const ConvWgradImgParams p) {
+    constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
+    constexpr int B_PLANES = (PASSES >= 3) ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __bf16* dzi = reinterpret_cast<__bf16*>(smem_raw);     // A_PLANES planes [npix_pad][PA]
+    __bf16* img = dzi + A_PLANES * p.dz_plane;             // B_PLANES planes of the input image
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = (int)blockIdx.x % p.n_col_groups, ig = (int)blockIdx.x / p.n_col_groups;
+    const int j0 = ig * p.G, j1 = min(p.n_img, j0 + p.G);
+    const int grp = lane >> 4, li = lane & 15, q = li >> 2, pq = li & 3;
+
+    // column tiles of this wave: global k' column of tile t = cg*NC + (wave + 4*t)*16
+    int col_off[NTW];  // element offset inside the input image contributed by the tile's tap / channel / lane part
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int c0 = cg * p.NC + (wave + 4 * t) * 16;
+        if constexpr (U8) {
+            const int c = c0 >> 6, ky0 = (c0 >> 3) & 7;  // the 16 columns are (ky0, kx 0..7), (ky0+1, kx 0..7)
+            col_off[t] = (c * p.R + ky0 + (pq >> 1)) * p.Wp + 4 * (pq & 1);
+        } else {
+            uint32_t tap, ci, ky, kx;
+            g.d_cinp.divmod((uint32_t)(c0 < g.K ? c0 : 0), tap, ci);
+            g.d_ksz.divmod(tap, ky, kx);
+            col_off[t] = ((int)ky * p.Wp + (int)kx) * g.cin_p + (int)ci + 4 * pq;
+        }
+    }
+
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = p.npix_pad / GEMM_BK;
+    for (int j = j0; j < j1; ++j) {
+        __syncthreads();  // previous image fully consumed
+        // ---- dz image: [npix_pad][PA], rows >= npix are zero ----
+        {
+            constexpr int FILL_BATCH = 8;
+            const int cpr = g.cout_p / 8;
+            const int n_chunks = p.npix_pad * cpr;
+            for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
+                float v[FILL_BATCH][8];
+                int dst[FILL_BATCH];
+#pragma unroll
+                for (int u = 0; u < FILL_BATCH; ++u) {
+                    const int c0 = cb + u * GEMM_THREADS + tid;
+                    const bool on = c0 < n_chunks;
+                    const int cq = on ? c0 : 0;
+                    const int cc = cq % cpr, pix = cq / cpr;
+                    const bool ok = on && pix < g.npix;
+                    load8_aligned(p.dz + (ok ? ((int64_t)j * g.npix + pix) * g.cout_p + cc * 8 : (int64_t)0), v[u]);
+                    mask8(ok, v[u]);
+                    dst[u] = on ? (pix * p.PA + cc * 8) : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < FILL_BATCH; ++u) {
+                    bf16x8 hi, lo;
+                    if constexpr (PASSES >= 2) {
+                        split8(v[u], hi, lo);
+                        if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(dzi + p.dz_plane + dst[u]) = lo;
+                    } else {
+                        round8(v[u], hi);
+                    }
+                    if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(dzi + dst[u]) = hi;
+                }
+            }
+        }
+        fill_input_image<U8, PASSES>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, tid);
+        __syncthreads();
+
+        for (int ks = 0; ks < nsteps; ++ks) {
+            // the two 4-row blocks of this lane's 8-pixel group
+            int pixoff[2], arow[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int kp = ks * GEMM_BK + 8 * grp + 4 * h + q;
+                arow[h] = kp * p.PA + 4 * pq;
+                kp = kp < g.npix ? kp : g.npix - 1;  // padded pixels: dz rows are zero, the input only has to be finite
+                uint32_t oy, ox;
+                g.d_wout.divmod((uint32_t)kp, oy, ox);
+                pixoff[h] = U8 ? ((int)oy * g.stride * p.Wp + (int)ox * g.stride)
+                               : ((int)oy * g.stride * p.Wp + (int)ox * g.stride) * g.cin_p;
+            }
+            bf16x8 fa_hi[MT], fa_lo[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                fa_hi[mt] = tr_frag(dzi + arow[0] + mt * 16, dzi + arow[1] + mt * 16);
+                if constexpr (PASSES >= 2)
+                    fa_lo[mt] = tr_frag(dzi + p.dz_plane + arow[0] + mt * 16, dzi + p.dz_plane + arow[1] + mt * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const __bf16* b0 = img + pixoff[0] + col_off[t];
+                const __bf16* b1 = img + pixoff[1] + col_off[t];
+                bf16x8 fb_hi = tr_frag(b0, b1), fb_lo;
+                if constexpr (PASSES >= 3) fb_lo = tr_frag(b0 + p.in_plane, b1 + p.in_plane);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if constexpr (PASSES >= 3)
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_lo, acc[mt][t], 0, 0, 0);
+                    if constexpr (PASSES >= 2)
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[mt], fb_hi, acc[mt][t], 0, 0, 0);
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_hi, acc[mt][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float* slab = p.slabs + (int64_t)ig * g.cout_p * g.K;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int col = cg * p.NC + (wave + 4 * t) * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = mt * 16 + grp * 4 + r;
+                if (row < g.cout_p && col < g.K) slab[(int64_t)row * g.K + col] = acc[mt][t][r] * p.scale;
+            }
+        }
+}
+
+template <int MT, int NTW, int PASSES, bool U8>
+static int launch_conv_wgrad_img(const ConvWgradImgParams& p, int n_img_groups, hipStream_t st) {
+    constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
+    constexpr int B_PLANES = (PASSES >= 3) ? 2 : 1;
+    const int lds = (A_PLANES * p.dz_plane + B_PLANES * p.in_plane) * 2;
+    static int configured_for = 0;
+    if (lds > 65536 && lds > configured_for) {
+        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_img_kernel<MT, NTW, PASSES, U8>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured_for = lds;
+    }
+    hipLaunchKernelGGL((conv_wgrad_img_kernel<MT, NTW, PASSES, U8>), dim3(n_img_groups * p.n_col_groups),
+                       dim3(GEMM_THREADS), lds, st, p);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
 }  // namespace isdqn

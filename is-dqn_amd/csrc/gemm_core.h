@@ -31,6 +31,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_THREADS = 256;
 
+// Workgroup ids are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2).  This bijective remap gives
+// every XCD a CONTIGUOUS range of logical tile ids, so tiles that share an operand panel (consecutive logical
+// ids) hit the same L2 instead of each re-fetching the panel from the Infinity Cache.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int n_blocks) {
+    const int xcd = bid & 7, q = n_blocks >> 3, r = n_blocks & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
 #define LDS_AS __attribute__((address_space(3)))
 
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
@@ -95,7 +104,8 @@ struct GemmTraits {
     using GA = TileGeom<BM, P::A_TR>;
     using GB = TileGeom<BN, P::B_TR>;
     static constexpr int STAGE_ELEMS = A_PLANES * GA::ELEMS + B_PLANES * GB::ELEMS;
-    static constexpr int LDS_BYTES = 2 * STAGE_ELEMS * 2;
+    static constexpr int PIPE_BYTES = 2 * STAGE_ELEMS * 2;
+    static constexpr int LDS_BYTES = PIPE_BYTES > P::EPI_LDS_BYTES ? PIPE_BYTES : P::EPI_LDS_BYTES;
 };
 
 template <class P>
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
             __syncthreads();
         }
     }
-    p.epilogue(tile, acc, tile.m0 + wave_m, tile.n0 + wave_n, lane);
+    p.epilogue(tile, acc, tile.m0 + wave_m, tile.n0 + wave_n, lane, smem_raw);
 }
 
 template <class P>

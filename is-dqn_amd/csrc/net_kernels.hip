@@ -690,6 +690,53 @@ static int launch_conv_wgrad(const Layer& l, const NetInput& in, const float* ac
     p.splits = ceil_div(ksteps, p.steps_per_split);
     return launch_gemm(p, p.tiles_n * p.splits, st);
 }
+// image-resident weight gradient (conv_img.h); *slabs_out = 0 when the layer does not qualify
+static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const float* act_in, const float* dz, float* slabs,
+                          int n_img, hipStream_t st, int* slabs_out) {
+    *slabs_out = 0;
+    if (!l.wgi_ntw || n_img != 0 && ceil_div(n_img, l.wgi_G) > l.gw_slabs) return ISDQN_OK;
+    ConvWgradImgParams wp;
+    wp.g = conv_geom(l);
+    const int passes = x3 ? (l.is_u8 ? 2 : 3) : 1;
+    const int mt = l.cout_p <= 32 ? 2 : 4;
+    int lds_unused_R, Wp, plane;
+    conv_img_geometry(wp.g, l.is_u8, l.cin, 1, mt, 1, lds_unused_R, Wp, plane);
+    wp.R = l.stride * (l.hout - 1) + l.ksz;  // the whole image
+    wp.Wp = Wp;
+    wp.in_plane = l.is_u8 ? l.cin * wp.R * Wp : wp.R * Wp * l.cin_p;
+    wp.PA = l.cout_p + 8;
+    wp.npix_pad = round_up(l.npix, 32);
+    wp.dz_plane = wp.npix_pad * wp.PA;
+    const int lds = ((passes >= 2 ? 2 : 1) * wp.dz_plane + (passes >= 3 ? 2 : 1) * wp.in_plane) * 2;
+    if (lds > 150 * 1024 || (l.is_u8 && (l.win < 8 || l.cin > 16))) return ISDQN_OK;
+    wp.dz = dz; wp.in = act_in;
+    wp.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win};
+    wp.slabs = slabs;
+    wp.scale = l.is_u8 ? (1.0f / 255.0f) : 1.0f;
+    wp.n_img = n_img; wp.G = l.wgi_G;
+    wp.NC = 64 * l.wgi_ntw;
+    wp.n_col_groups = l.K / wp.NC;
+    const int groups = ceil_div(n_img, l.wgi_G);
+    *slabs_out = groups;
+#define WGI(MT_, NTW_, P_, U_) return launch_conv_wgrad_img<MT_, NTW_, P_, U_>(wp, groups, st)
+    if (l.is_u8) {
+        if (mt == 2) { if (l.wgi_ntw == 4) { if (passes == 2) WGI(2, 4, 2, true); else WGI(2, 4, 1, true); }
+                       if (l.wgi_ntw == 2) { if (passes == 2) WGI(2, 2, 2, true); else WGI(2, 2, 1, true); } }
+        else         { if (l.wgi_ntw == 4) { if (passes == 2) WGI(4, 4, 2, true); else WGI(4, 4, 1, true); }
+                       if (l.wgi_ntw == 2) { if (passes == 2) WGI(4, 2, 2, true); else WGI(4, 2, 1, true); } }
+    } else {
+        if (mt == 2) { if (l.wgi_ntw == 4) { if (passes == 3) WGI(2, 4, 3, false); else WGI(2, 4, 1, false); }
+                       if (l.wgi_ntw == 3) { if (passes == 3) WGI(2, 3, 3, false); else WGI(2, 3, 1, false); }
+                       if (l.wgi_ntw == 2) { if (passes == 3) WGI(2, 2, 3, false); else WGI(2, 2, 1, false); } }
+        else         { if (l.wgi_ntw == 4) { if (passes == 3) WGI(4, 4, 3, false); else WGI(4, 4, 1, false); }
+                       if (l.wgi_ntw == 3) { if (passes == 3) WGI(4, 3, 3, false); else WGI(4, 3, 1, false); }
+                       if (l.wgi_ntw == 2) { if (passes == 3) WGI(4, 2, 3, false); else WGI(4, 2, 1, false); } }
+    }
+#undef WGI
+    *slabs_out = 0;  // (u8 with NTW 3 is not instantiated)
+    return ISDQN_OK;
+}
+
 static int conv_wgrad_slabs(const Layer& l, int n_img) {
     int ksteps = ceil_div(n_img * l.npix, GEMM_BK);
     int sps = ceil_div(ksteps, l.gw_slabs);
@@ -889,11 +936,18 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         int w_slabs;
         bool fused_adam = false;
         if (l.kind == 0) {
+            int img_slabs = 0;
+            rc = conv_wgrad_img(l, x3, in, act_in, dz_cur, ws + l.gw_off, B, st, &img_slabs);
+            if (rc) return rc;
+            if (img_slabs) {
+                w_slabs = img_slabs;
+            } else {
             if (l.is_u8) rc = x3 ? launch_conv_wgrad<2, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, st)
                                  : launch_conv_wgrad<1, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, st);
             else rc = x3 ? launch_conv_wgrad<3, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, st)
                          : launch_conv_wgrad<1, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, st);
             w_slabs = conv_wgrad_slabs(l, B);
+            }
         } else {
             // dW[out][in_p] = sum_b dz[b][out] * a[b][in_p] : both operands stored [K = b][rows]
             MatSrc A{dz_cur, dz_ld, B, l.out_p, 1};

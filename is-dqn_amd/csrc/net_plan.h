@@ -32,6 +32,8 @@ struct Layer {
     int64_t act_off, z_off, dz_off, gw_off, part_off;
     int gw_slabs;   // split-K slabs of the weight gradient
     int fwd_splits; // dense: split-K factor of the forward GEMM
+    // conv: image-resident weight gradient (conv_img.h): 0 = use the generic engine
+    int wgi_ntw, wgi_G, wgi_groups;
     char name[16];
     char ln_name[16];
 };
@@ -190,6 +192,21 @@ static inline int build_plan(const isdqn_net_config* cfg, Plan& P) {
             if (s < 1) s = 1;
             if (s > ksteps) s = ksteps;
             l.gw_slabs = s;
+            // image-resident variant: column groups of 64*NTW k' columns x groups of G images ~ 256 workgroups
+            l.wgi_ntw = 0;
+            if (l.K % 64 == 0 && (l.is_u8 || l.cin_p % 16 == 0)) {
+                int ntw = (l.K % 256 == 0) ? 4 : (l.K % 192 == 0) ? 3 : (l.K % 128 == 0) ? 2 : 0;
+                if (l.K == 512) ntw = 2;
+                if (ntw) {
+                    int ncg = l.K / (64 * ntw);
+                    int G = (P.B * ncg + 255) / 256;
+                    if (G < 1) G = 1;
+                    l.wgi_ntw = ntw;
+                    l.wgi_G = G;
+                    l.wgi_groups = ceil_div(P.B, G);
+                    if (l.wgi_groups > l.gw_slabs) l.gw_slabs = l.wgi_groups;
+                }
+            }
         } else {
             int tiles = ceil_div(l.out_p, 128) * ceil_div(l.in_p, 128);
             int ksteps = ceil_div(P.B, 32);

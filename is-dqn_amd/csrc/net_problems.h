@@ -81,10 +81,12 @@ struct PlainGemm {
     int tiles_m, tiles_n, splits, steps_per_split;
     int64_t slab_stride;
     AdamFuse adam;
+    static constexpr int EPI_LDS_BYTES = ADAM ? BM_ * (BN_ + 4) * 4 : 0;
     struct Tile { int m0, n0, k0, k1, split; };
     struct ACtx { int fixed; };
     struct BCtx { int fixed; };
     __device__ __forceinline__ bool tile(int bid, Tile& t) const {
+        bid = xcd_remap(bid, tiles_m * tiles_n * splits);  // m-tiles of one (n-tile, split) share an XCD
         int tm = bid % tiles_m, rest = bid / tiles_m;
         int tn = rest % tiles_n;
         t.split = rest / tiles_n;
@@ -116,29 +118,48 @@ struct PlainGemm {
         else B.load<AL>(var, c.fixed, v);
     }
     template <int MT, int NT>
-    __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const {
+    __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane, char* smem) const {
         if constexpr (ADAM) {
-            const float c1 = adam.consts[0], c2 = adam.consts[1];
+            // The MFMA accumulator layout gives each lane 4 rows x 1 column: straight to memory that is 64-byte
+            // pieces of p/m/v rows.  Stage the gradient tile in LDS and let every thread own float4s of a row,
+            // so parameters and moments move as full coalesced rows (16 B per lane, 512 B per row of the tile).
+            constexpr int LD = BN + 4;
+            float* tg = reinterpret_cast<float*>(smem);
+            const int lm = m_wave - t.m0, ln = n_wave - t.n0;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    int col = n_wave + nt * 16 + (lane & 15);
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int row = m_wave + mt * 16 + (lane >> 4) * 4 + r;
-                        if (row < M && col < N) {
-                            const int64_t i = (int64_t)row * ldc + col;
-                            const float g = acc[mt][nt][r];
-                            if (adam.grad_out) adam.grad_out[i] = g;
-                            const float mm = adam.b1 * adam.m[i] + (1.f - adam.b1) * g;
-                            const float vv = adam.b2 * adam.v[i] + (1.f - adam.b2) * g * g;
-                            adam.m[i] = mm;
-                            adam.v[i] = vv;
-                            adam.p[i] = adam.p[i] - adam.lr * ((mm / c1) / (sqrtf(vv / c2) + adam.eps));
-                        }
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        tg[(lm + mt * 16 + (lane >> 4) * 4 + r) * LD + ln + nt * 16 + (lane & 15)] = acc[mt][nt][r];
+            __syncthreads();
+            const float c1 = adam.consts[0], c2 = adam.consts[1];
+            const int tid = threadIdx.x;
+            for (int i = tid; i < BM * (BN / 4); i += GEMM_THREADS) {
+                const int rl = i / (BN / 4), c4 = (i % (BN / 4)) * 4;
+                const int row = t.m0 + rl, col = t.n0 + c4;
+                if (row >= M || col >= N) continue;  // N and ldc are multiples of 4: a float4 never straddles the edge
+                const float4 g = *reinterpret_cast<const float4*>(tg + rl * LD + c4);
+                const int64_t o = (int64_t)row * ldc + col;
+                if (adam.grad_out) *reinterpret_cast<float4*>(adam.grad_out + o) = g;
+                float4 pm = *reinterpret_cast<const float4*>(adam.m + o);
+                float4 pv = *reinterpret_cast<const float4*>(adam.v + o);
+                float4 pp = *reinterpret_cast<const float4*>(adam.p + o);
+                const float* gp = &g.x;
+                float* mp = &pm.x; float* vp = &pv.x; float* xp = &pp.x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float mm = adam.b1 * mp[r] + (1.f - adam.b1) * gp[r];
+                    const float vv = adam.b2 * vp[r] + (1.f - adam.b2) * gp[r] * gp[r];
+                    mp[r] = mm;
+                    vp[r] = vv;
+                    xp[r] = xp[r] - adam.lr * ((mm / c1) / (sqrtf(vv / c2) + adam.eps));
                 }
+                *reinterpret_cast<float4*>(adam.m + o) = pm;
+                *reinterpret_cast<float4*>(adam.v + o) = pv;
+                *reinterpret_cast<float4*>(adam.p + o) = pp;
+            }
             return;
         }
         float* c = C + (int64_t)t.split * slab_stride;
@@ -170,6 +191,7 @@ template <int BM_, int PASSES_, bool U8>
 struct ConvFwd {
     static constexpr int BM = BM_, BN = 128, WM = 1, WN = 4, PASSES = PASSES_;
     static constexpr bool A_TR = false, B_TR = false;
+    static constexpr int EPI_LDS_BYTES = 0;
     ConvGeom g;
     MatSrc W;            // [cout_p][K]
     const float* in;     // fp32 NHWC input (if !U8)
@@ -225,7 +247,7 @@ struct ConvFwd {
         }
     }
     template <int MT, int NT>
-    __device__ __forceinline__ void epilogue(const Tile&, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const {
+    __device__ __forceinline__ void epilogue(const Tile&, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane, char* smem) const {
         const int grp = lane >> 4;
         float bi[MT][4], ga[MT][4], be[MT][4];
 #pragma unroll
@@ -294,6 +316,7 @@ template <int BM_, int PASSES_>
 struct ConvDgrad {
     static constexpr int BM = BM_, BN = 128, WM = 1, WN = 4, PASSES = PASSES_;
     static constexpr bool A_TR = true, B_TR = false;
+    static constexpr int EPI_LDS_BYTES = 0;
     ConvGeom g;
     const float* W;   // [cout_p][taps][cin_p]
     const float* dz;  // [n_img][hout][wout][cout_p]
@@ -355,7 +378,7 @@ struct ConvDgrad {
         mask8(ok, v);
     }
     template <int MT, int NT>
-    __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const {
+    __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane, char* smem) const {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             int q = n_wave + nt * 16 + (lane & 15);
@@ -380,6 +403,7 @@ template <int PASSES_, bool U8>
 struct ConvWgrad {
     static constexpr int BM = 64, BN = 64, WM = 2, WN = 2, PASSES = PASSES_;
     static constexpr bool A_TR = true, B_TR = true;
+    static constexpr int EPI_LDS_BYTES = 0;
     ConvGeom g;
     MatSrc DZ;        // [n_pix][cout_p]: outer = pixels (K), inner = cout_p
     const float* in;  // fp32 NHWC input (if !U8)
@@ -431,7 +455,7 @@ struct ConvWgrad {
         }
     }
     template <int MT, int NT>
-    __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const {
+    __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane, char* smem) const {
         float* c = slabs + (int64_t)t.split * g.cout_p * g.K;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
