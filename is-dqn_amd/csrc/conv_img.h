@@ -27,6 +27,7 @@ struct ConvImgParams {
     int n_img, z_img;
     int tiles_per_img;       // ceil(npix / 128)
     int R, Wp;               // local rows / padded width of the LDS image
+    int PP;                  // fp32 layers: pixel pitch in elements (cin_p + pad: spreads consecutive pixels over LDS banks)
     int plane_elems;         // bf16 elements of one precision plane of the image
     int ablate;              // profiling only (env ISDQN_ABLATE): 1 skip fill, 2 skip K loop, 4 skip epilogue, 8 skip weight fetch
 };
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
                 const bool ok = on && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
                 load8_aligned(p.in + (ok ? (((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + cc * 8 : (int64_t)0), v[u]);
                 mask8(ok, v[u]);
-                dst[u] = on ? (pix * g.cin_p + cc * 8) : -1;
+                dst[u] = on ? (pix * p.PP + cc * 8) : -1;
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
         const int oy = pp / g.wout, ox = pp - oy * g.wout;
         const int ly0 = oy * g.stride - g.pad - row_base;  // >= 0 by construction
         const int lx0 = ox * g.stride;                     // padded column of tap kx = 0
-        b_org[nt] = U8 ? (ly0 * p.Wp + lx0) : (ly0 * p.Wp + lx0) * g.cin_p;
+        b_org[nt] = U8 ? (ly0 * p.Wp + lx0) : (ly0 * p.Wp + lx0) * p.PP;
     }
     const int grp = lane >> 4;
 
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
             uint32_t tap, ci, ky, kx;
             g.d_cinp.divmod((uint32_t)kq, tap, ci);
             g.d_ksz.divmod(tap, ky, kx);
-            tap_off = ((int)ky * p.Wp + (int)kx) * g.cin_p + (int)ci;
+            tap_off = ((int)ky * p.Wp + (int)kx) * p.PP + (int)ci;
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -324,7 +325,7 @@ static int launch_conv_fwd_img(const ConvImgParams& p, hipStream_t st) {
 
 // LDS bytes the image-resident kernel would need for this layer (host-side feasibility check)
 static inline int conv_img_geometry(const ConvGeom& g, bool u8, int stack, int b_planes, int mt, int a_planes, int& R,
-                                    int& Wp, int& plane_elems) {
+                                    int& Wp, int& plane_elems, int pixel_pitch = 0) {
     int rows_per_tile = g.npix <= 128 ? g.hout : ((128 + g.wout - 2) / g.wout + 1);
     if (rows_per_tile > g.hout) rows_per_tile = g.hout;
     R = g.stride * (rows_per_tile - 1) + g.ksz;
@@ -333,7 +334,7 @@ static inline int conv_img_geometry(const ConvGeom& g, bool u8, int stack, int b
         plane_elems = stack * R * Wp;
     } else {
         Wp = (g.wout - 1) * g.stride + g.ksz;           // = win + pad_lo + pad_hi
-        plane_elems = R * Wp * g.cin_p;
+        plane_elems = R * Wp * (pixel_pitch ? pixel_pitch : g.cin_p);
     }
     const int a_stage = a_planes * (mt * 16) * (GEMM_BK + 8);
     return (2 * a_stage + b_planes * plane_elems) * 2;
@@ -578,6 +579,366 @@ static int launch_conv_wgrad_img(const ConvWgradImgParams& p, int n_img_groups, 
     }
     hipLaunchKernelGGL((conv_wgrad_img_kernel<MT, NTW, PASSES, U8>), dim3(n_img_groups * p.n_col_groups),
                        dim3(GEMM_THREADS), lds, st, p);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
+
+// =====================================================================================================
+// Image-resident data gradient with the LayerNorm + ReLU backward of the layer below fused in
+// =====================================================================================================
+//   da[iy,ix,ci] = sum_{jy,jx,co} dz[(iy+pad-ky)/s, (ix+pad-kx)/s, co] * W[co][ky][kx][ci],  ky = py + s*jy
+// One workgroup = (image, stride-parity class, 128-pixel tile of that class).  The dz image of the layer
+// ([hout][wout][cout_p], zero border of T-1 pixels top/left and `bh` bottom/right) sits in LDS; the B fragments
+// of all taps are ds_reads at a per-lane offset; only the weight K-slices stream (TR image: the contraction
+// index (tap, co) is the slow one of W[co][tap][ci]).  M = input channels, so each input pixel's channels sit in
+// 4 lanes x MT*4 registers and the backward of  a = relu(LN(z))  of the layer below runs in the epilogue:
+//   xhat = (z-mean)*rstd ; dy = da*[xhat*gamma+beta > 0] ; g = dy*gamma
+//   dz_in = rstd*(g - mean(g) - xhat*mean(g*xhat)) ; dgamma += dy*xhat ; dbeta += dy ; dbias += dz_in
+// `da` never goes to HBM.  Per-workgroup partial sums of (dgamma, dbeta, dbias) go to part[wg][3][cin_p].
+struct ConvDgradImgParams {
+    ConvGeom g;          // geometry of THIS conv layer (dz is its output gradient, da its input gradient)
+    const float* W;      // [cout_p][taps][cin_p]
+    const float* dz;     // [n_img][hout][wout][cout_p]
+    const float* z_in;   // pre-LayerNorm output of the layer below  [n_img][hin][win][cin_p]
+    const float *gamma, *beta;  // LayerNorm of the layer below (nullptr: no LayerNorm, ReLU only)
+    int c_in;            // true channel count of the layer below
+    float* dz_in;        // [n_img][hin][win][cin_p]
+    float* part;         // [n_wg][3][cin_p]
+    int n_img, T, Kc;    // taps per dim per class, K of a class = T*T*cout_p
+    int Hd, Wd, PPd, bt; // padded dz image rows / cols, pixel pitch (elements), top/left border
+    int dz_plane;
+    int tiles_per_img;   // sum over classes of ceil(class pixels / 128)
+    int cls_tile_start[5];
+    FastDiv cls_d_w[4];  // per class: divide by Wb (pixels per class row)
+    int n_classes;
+};
+
+template <int MT, int PASSES>
+__global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const ConvDgradImgParams p) {
+    constexpr int NT = 2;
+    constexpr int BM = MT * 16;
+    constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
+    constexpr int B_PLANES = PASSES >= 3 ? 2 : 1;
+    using GA = TileGeom<BM, true>;  // weights: TR image [32 k][BM ci]
+    constexpr int A_STAGE = A_PLANES * GA::ELEMS;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __bf16* a_stage = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* img = a_stage + 2 * A_STAGE;
+    __shared__ float s_part[4][3][64];
+    const ConvGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4;
+
+    const int j = (int)blockIdx.x / p.tiles_per_img;
+    int tl = (int)blockIdx.x - j * p.tiles_per_img;
+    int cls = 0;
+    while (cls + 1 < p.n_classes && tl >= p.cls_tile_start[cls + 1]) ++cls;
+    const int q0 = (tl - p.cls_tile_start[cls]) * 128;  // first class-local pixel of this tile
+    const int cy = cls / g.stride, cx = cls % g.stride;
+    const int Ha = (g.hin - cy + g.stride - 1) / g.stride, Wb = (g.win - cx + g.stride - 1) / g.stride;
+    const int n_cls_pix = Ha * Wb;
+    const int py = (cy + g.pad) % g.stride, px = (cx + g.pad) % g.stride;
+
+    // ---- dz image of this sample into LDS (zero border) ----
+    {
+        constexpr int FILL_BATCH = 8;
+        const int cpp = g.cout_p / 8;
+        const int n_chunks = p.Hd * p.Wd * cpp;
+        for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
+            float v[FILL_BATCH][8];
+            int dst[FILL_BATCH];
+#pragma unroll
+            for (int u = 0; u < FILL_BATCH; ++u) {
+                const int c0 = cb + u * GEMM_THREADS + tid;
+                const bool on = c0 < n_chunks;
+                const int cq = on ? c0 : 0;
+                const int cc = cq % cpp, pix = cq / cpp;
+                const int xp = pix % p.Wd, yp = pix / p.Wd;
+                const int oy = yp - p.bt, ox = xp - p.bt;
+                const bool ok = on && oy >= 0 && oy < g.hout && ox >= 0 && ox < g.wout;
+                load8_aligned(p.dz + (ok ? (((int64_t)j * g.hout + oy) * g.wout + ox) * g.cout_p + cc * 8 : (int64_t)0), v[u]);
+                mask8(ok, v[u]);
+                dst[u] = on ? (pix * p.PPd + cc * 8) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < FILL_BATCH; ++u) {
+                bf16x8 hi, lo;
+                if constexpr (PASSES >= 3) {
+                    split8(v[u], hi, lo);
+                    if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + p.dz_plane + dst[u]) = lo;
+                } else {
+                    round8(v[u], hi);
+                }
+                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
+            }
+        }
+    }
+
+    // ---- per-lane pixel of the two column tiles ----
+    int b_org[NT], pix_iy[NT], pix_ix[NT];
+    bool pix_ok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int q = q0 + wave * 32 + nt * 16 + (lane & 15);
+        pix_ok[nt] = q < n_cls_pix;
+        q = pix_ok[nt] ? q : n_cls_pix - 1;
+        uint32_t a, b;
+        p.cls_d_w[cls].divmod((uint32_t)q, a, b);
+        const int iy = cy + g.stride * (int)a, ix = cx + g.stride * (int)b;
+        pix_iy[nt] = iy; pix_ix[nt] = ix;
+        const int oyb = (iy + g.pad - py) / g.stride, oxb = (ix + g.pad - px) / g.stride;
+        b_org[nt] = ((oyb + p.bt) * p.Wd + oxb + p.bt) * p.PPd;
+    }
+
+    // ---- weight K-slice staging: TR image [32 k][BM ci], chunk = 8 consecutive ci of one (tap, co) ----
+    constexpr int A_PER = GA::PER_THREAD;
+    int a_ci0[A_PER], a_kk[A_PER], a_lds[A_PER];
+    bool a_on[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        int c = tid + i * GEMM_THREADS;
+        a_on[i] = c < GA::CHUNKS;
+        if (!a_on[i]) c = 0;
+        const int kk = c / (BM / 8), rc = c % (BM / 8);
+        a_ci0[i] = rc * 8; a_kk[i] = kk;
+        a_lds[i] = kk * GA::PITCH + rc * 8;
+    }
+    float sa[A_PER][8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int k = k0 + a_kk[i];
+            const bool ok = (k < p.Kc) && (a_ci0[i] < g.cin_p);
+            uint32_t jt, co;
+            g.d_coutp.divmod(ok ? (uint32_t)k : 0u, jt, co);
+            const int jy = (int)jt / p.T, jx = (int)jt % p.T;
+            const int ky = py + g.stride * jy, kx = px + g.stride * jx;
+            load8_aligned(p.W + (ok ? (int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + a_ci0[i] : (int64_t)0), sa[i]);
+            mask8(ok, sa[i]);
+        }
+    };
+    auto stash = [&](int stage) {
+        __bf16* a_hi = a_stage + stage * A_STAGE;
+        __bf16* a_lo = a_hi + GA::ELEMS;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            if (!a_on[i]) continue;
+            bf16x8 hi, lo;
+            if constexpr (PASSES >= 2) {
+                split8(sa[i], hi, lo);
+                *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
+            } else {
+                round8(sa[i], hi);
+            }
+            *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (p.Kc + GEMM_BK - 1) / GEMM_BK;
+    const int k_last = p.Kc - 8;
+    auto compute = [&](int stage, int kk) {
+        const __bf16* a_hi = a_stage + stage * A_STAGE;
+        const __bf16* a_lo = a_hi + GA::ELEMS;
+        bf16x8 fa_hi[MT], fa_lo[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            fa_hi[mt] = read_frag<true, GA::PITCH>(a_hi, mt * 16, lane);
+            if constexpr (PASSES >= 2) fa_lo[mt] = read_frag<true, GA::PITCH>(a_lo, mt * 16, lane);
+        }
+        int kq = kk * GEMM_BK + grp * 8;
+        kq = kq < k_last ? kq : k_last;
+        uint32_t jt, co;
+        g.d_coutp.divmod((uint32_t)kq, jt, co);
+        const int jy = (int)jt / p.T, jx = (int)jt % p.T;
+        const int tap_off = -(jy * p.Wd + jx) * p.PPd + (int)co;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const __bf16* src = img + b_org[nt] + tap_off;
+            bf16x8 fb_hi = *reinterpret_cast<const bf16x8*>(src), fb_lo;
+            if constexpr (PASSES >= 3) fb_lo = *reinterpret_cast<const bf16x8*>(src + p.dz_plane);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (PASSES >= 3)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_lo, acc[mt][nt], 0, 0, 0);
+                if constexpr (PASSES >= 2)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[mt], fb_hi, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_hi, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    };
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more = s + 1 < nsteps;
+        if (more) fetch((s + 1) * GEMM_BK);
+        compute(s & 1, s);
+        if (more) stash((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: LayerNorm + ReLU backward of the layer below, per input pixel (column) ----
+    float ga[MT][4], be[MT][4];
+    float dg[MT][4], db[MT][4], dbias[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = mt * 16 + grp * 4 + r;
+            const bool ok = ch < p.c_in;
+            ga[mt][r] = (ok && p.gamma) ? p.gamma[ch] : 1.f;
+            be[mt][r] = (ok && p.gamma) ? p.beta[ch] : 0.f;
+            dg[mt][r] = db[mt][r] = dbias[mt][r] = 0.f;
+        }
+    const float inv_c = 1.f / (float)p.c_in;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t pixel = ((int64_t)j * g.hin + pix_iy[nt]) * g.win + pix_ix[nt];
+        float zv[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int ch0 = mt * 16 + grp * 4;
+            float4 zq = float4{0.f, 0.f, 0.f, 0.f};
+            if (ch0 < g.cin_p) zq = *reinterpret_cast<const float4*>(p.z_in + pixel * g.cin_p + ch0);
+            zv[mt][0] = zq.x; zv[mt][1] = zq.y; zv[mt][2] = zq.z; zv[mt][3] = zq.w;
+        }
+        float out[MT][4];
+        if (p.gamma != nullptr) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (mt * 16 + grp * 4 + r) < p.c_in;
+                    s1 += ok ? zv[mt][r] : 0.f;
+                    s2 += ok ? zv[mt][r] * zv[mt][r] : 0.f;
+                }
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            const float mean = s1 * inv_c;
+            const float rstd = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + 1e-6f);
+            float xh[MT][4], gg[MT][4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = pix_ok[nt] && (mt * 16 + grp * 4 + r) < p.c_in;
+                    xh[mt][r] = (zv[mt][r] - mean) * rstd;
+                    const float y = xh[mt][r] * ga[mt][r] + be[mt][r];
+                    const float dy = (ok && y > 0.f) ? acc[mt][nt][r] : 0.f;
+                    dg[mt][r] += dy * xh[mt][r];
+                    db[mt][r] += dy;
+                    gg[mt][r] = dy * ga[mt][r];
+                    m1 += gg[mt][r];
+                    m2 += gg[mt][r] * xh[mt][r];
+                }
+            m1 += __shfl_xor(m1, 16); m1 += __shfl_xor(m1, 32);
+            m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
+            m1 *= inv_c;
+            m2 *= inv_c;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = pix_ok[nt] && (mt * 16 + grp * 4 + r) < p.c_in;
+                    out[mt][r] = ok ? rstd * (gg[mt][r] - m1 - xh[mt][r] * m2) : 0.f;
+                    dbias[mt][r] += out[mt][r];
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = pix_ok[nt] && (mt * 16 + grp * 4 + r) < p.c_in;
+                    out[mt][r] = (ok && zv[mt][r] > 0.f) ? acc[mt][nt][r] : 0.f;
+                    dbias[mt][r] += out[mt][r];
+                }
+        }
+        if (pix_ok[nt]) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ch0 = mt * 16 + grp * 4;
+                if (ch0 < g.cin_p)
+                    *reinterpret_cast<float4*>(p.dz_in + pixel * g.cin_p + ch0) =
+                        float4{out[mt][0], out[mt][1], out[mt][2], out[mt][3]};
+            }
+        }
+    }
+    // ---- partial sums: over the 16 pixel lanes of a group, then over the 4 waves ----
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                dg[mt][r] += __shfl_xor(dg[mt][r], off);
+                db[mt][r] += __shfl_xor(db[mt][r], off);
+                dbias[mt][r] += __shfl_xor(dbias[mt][r], off);
+            }
+            if ((lane & 15) == 0) {
+                const int ch = mt * 16 + grp * 4 + r;
+                s_part[wave][0][ch] = dg[mt][r];
+                s_part[wave][1][ch] = db[mt][r];
+                s_part[wave][2][ch] = dbias[mt][r];
+            }
+        }
+    __syncthreads();
+    for (int i = tid; i < 3 * g.cin_p; i += GEMM_THREADS) {
+        const int which = i / g.cin_p, c = i % g.cin_p;
+        p.part[((int64_t)blockIdx.x * 3 + which) * g.cin_p + c] =
+            s_part[0][which][c] + s_part[1][which][c] + s_part[2][which][c] + s_part[3][which][c];
+    }
+}
+
+// Deterministic reduction of per-workgroup partial rows: out[c] = sum_r part[r][c].  One workgroup per 8
+// columns; 32 row-lanes per column stride over the rows with 8 independent loads in flight, then a fixed
+// shuffle/LDS tree (same order every run).
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int n_rows, int width,
+                                                          float* __restrict__ out) {
+    __shared__ float s_red[32][8];
+    const int col = blockIdx.x * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;  // rl in [0, 32)
+    float s = 0.f;
+    if (col < width) {
+        int r = rl;
+        for (; r + 7 * 32 < n_rows; r += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(r + u * 32) * width + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < n_rows; r += 32) s += part[(int64_t)r * width + col];
+    }
+    s_red[rl][threadIdx.x & 7] = s;
+    __syncthreads();
+    if (rl == 0 && col < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += s_red[k][threadIdx.x & 7];
+        out[col] = t;
+    }
+}
+
+template <int MT, int PASSES>
+static int launch_conv_dgrad_img(const ConvDgradImgParams& p, hipStream_t st) {
+    constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
+    constexpr int B_PLANES = PASSES >= 3 ? 2 : 1;
+    using GA = TileGeom<MT * 16, true>;
+    const int lds = (2 * A_PLANES * GA::ELEMS + B_PLANES * p.dz_plane) * 2;
+    static int configured_for = 0;
+    if (lds > 65536 && lds > configured_for) {
+        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dgrad_img_kernel<MT, PASSES>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured_for = lds;
+    }
+    hipLaunchKernelGGL((conv_dgrad_img_kernel<MT, PASSES>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS), lds, st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
 }

@@ -489,8 +489,11 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     ip.g = conv_geom(l);
     const int mt = l.cout_p <= 32 ? 2 : 4;
     const int passes = x3 ? (l.is_u8 ? 2 : 3) : 1;
+    // pixel pitch: +8 / +16 elements so that the 16 pixels of an MFMA column tile do not share LDS banks
+    // (128-byte pixel rows put them 4-5 deep on the same banks; measured model in DESIGN.md)
+    ip.PP = l.is_u8 ? 0 : l.cin_p + (l.cin_p % 64 == 0 ? 16 : 8);
     const int lds = conv_img_geometry(ip.g, l.is_u8, l.cin, passes >= 3 ? 2 : 1, mt, passes >= 2 ? 2 : 1, ip.R, ip.Wp,
-                                      ip.plane_elems);
+                                      ip.plane_elems, ip.PP);
     if (lds > 150 * 1024 || (l.is_u8 && l.win < 8)) return ISDQN_OK;
     ip.W = MatSrc{params + l.w_off, l.K, l.cout_p, l.K, 1};
     ip.in = act_in;
@@ -737,6 +740,58 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
     return ISDQN_OK;
 }
 
+// image-resident data gradient of conv layer `l` fused with the LayerNorm/ReLU backward of layer `below`:
+// writes dz of `below` and the reduced (dgamma, dbeta, dbias) row of `below`.  *done = false: not applicable.
+static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const float* params, const float* dz, float* ws,
+                          int n_img, hipStream_t st, bool* done) {
+    *done = false;
+    if (!l.dgi_tiles || below.part_rows < n_img * l.dgi_tiles) return ISDQN_OK;
+    ConvDgradImgParams dp;
+    dp.g = conv_geom(l);
+    dp.W = params + l.w_off;
+    dp.dz = dz;
+    dp.z_in = ws + below.z_off;
+    dp.gamma = below.has_ln ? params + below.g_off : nullptr;
+    dp.beta = below.has_ln ? params + below.be_off : nullptr;
+    dp.c_in = below.out_f;
+    dp.dz_in = ws + below.dz_off;
+    dp.part = ws + below.part_off;
+    dp.n_img = n_img;
+    dp.T = l.ksz / l.stride;
+    dp.Kc = dp.T * dp.T * l.cout_p;
+    dp.bt = dp.T - 1;
+    const int need_h = (l.hin - 1 + l.pad) / l.stride + 1, need_w = (l.win - 1 + l.pad) / l.stride + 1;
+    dp.Hd = dp.bt + (l.hout > need_h ? l.hout : need_h);
+    dp.Wd = dp.bt + (l.wout > need_w ? l.wout : need_w);
+    dp.PPd = l.cout_p + 8;
+    dp.dz_plane = dp.Hd * dp.Wd * dp.PPd;
+    dp.n_classes = l.stride * l.stride;
+    int acc = 0;
+    for (int c = 0; c < dp.n_classes; ++c) {
+        int cy = c / l.stride, cx = c % l.stride;
+        int Ha = (l.hin - cy + l.stride - 1) / l.stride, Wb = (l.win - cx + l.stride - 1) / l.stride;
+        dp.cls_tile_start[c] = acc;
+        dp.cls_d_w[c] = FastDiv((uint32_t)Wb);
+        acc += ceil_div(Ha * Wb, 128);
+    }
+    dp.cls_tile_start[dp.n_classes] = acc;
+    dp.tiles_per_img = acc;
+    const int mt = l.cin_p <= 32 ? 2 : 4;
+    const int passes = x3 ? 3 : 1;
+    const int lds = (2 * (passes >= 2 ? 2 : 1) * 32 * (mt * 16 + 8) + (passes >= 3 ? 2 : 1) * dp.dz_plane) * 2;
+    if (lds > 150 * 1024) return ISDQN_OK;
+    int rc;
+    if (passes == 3) rc = mt == 2 ? launch_conv_dgrad_img<2, 3>(dp, st) : launch_conv_dgrad_img<4, 3>(dp, st);
+    else rc = mt == 2 ? launch_conv_dgrad_img<2, 1>(dp, st) : launch_conv_dgrad_img<4, 1>(dp, st);
+    if (rc) return rc;
+    const int width = 3 * below.out_p;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(width, 8)), dim3(256), 0, st, ws + below.part_off,
+                       n_img * dp.tiles_per_img, width, ws + below.red_off);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    *done = true;
+    return ISDQN_OK;
+}
+
 static int conv_wgrad_slabs(const Layer& l, int n_img) {
     int ksteps = ceil_div(n_img * l.npix, GEMM_BK);
     int sps = ceil_div(ksteps, l.gw_slabs);
@@ -896,29 +951,44 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     };
     const float* dz_cur = ws + P.dout_off;  // gradient w.r.t. the current layer's pre-activation output
     int dz_ld = P.nha_p;
+    bool dz_fused = false;  // dz of layer i was already produced by the fused data gradient of layer i+1
     for (int i = P.n_layers - 1; i >= 0; --i) {
         const Layer& l = P.L[i];
         const float* act_in = i > 0 ? ws + P.L[i - 1].act_off : nullptr;
         if (!l.is_head) {
-            // da (w.r.t. this layer's activation) was left in ws+da_off by layer i+1's data-gradient
-            int rows = l.kind == 0 ? B * l.npix : B;
-            int nb = 0;
-            rc = ln_bwd(l, params, ws + P.da_off, ws + l.z_off, rows, ws + l.dz_off, ws + l.part_off, &nb, st);
-            if (rc) return rc;
             dz_cur = ws + l.dz_off;
             dz_ld = l.out_p;
-            if (l.has_ln) {
-                add_entry(l.g_off, l.out_p, ws + l.part_off, nb, 3 * (int64_t)l.out_p);
-                add_entry(l.be_off, l.out_p, ws + l.part_off + l.out_p, nb, 3 * (int64_t)l.out_p);
+            if (dz_fused) {
+                if (l.has_ln) {
+                    add_entry(l.g_off, l.out_p, ws + l.red_off, 1, 0);
+                    add_entry(l.be_off, l.out_p, ws + l.red_off + l.out_p, 1, 0);
+                }
+                add_entry(l.b_off, l.out_p, ws + l.red_off + 2 * l.out_p, 1, 0);
+            } else {
+                // da (w.r.t. this layer's activation) was left in ws+da_off by layer i+1's data-gradient
+                int rows = l.kind == 0 ? B * l.npix : B;
+                int nb = 0;
+                rc = ln_bwd(l, params, ws + P.da_off, ws + l.z_off, rows, ws + l.dz_off, ws + l.part_off, &nb, st);
+                if (rc) return rc;
+                if (l.has_ln) {
+                    add_entry(l.g_off, l.out_p, ws + l.part_off, nb, 3 * (int64_t)l.out_p);
+                    add_entry(l.be_off, l.out_p, ws + l.part_off + l.out_p, nb, 3 * (int64_t)l.out_p);
+                }
+                add_entry(l.b_off, l.out_p, ws + l.part_off + 2 * l.out_p, nb, 3 * (int64_t)l.out_p);
             }
-            add_entry(l.b_off, l.out_p, ws + l.part_off + 2 * l.out_p, nb, 3 * (int64_t)l.out_p);
         } else {
             add_entry(l.b_off, l.out_p, ws + P.dbh_off, 1, 0);
         }
         // data gradient for the layer below first: it reads this layer's weights, which the fused-Adam
         // weight-gradient epilogue below updates in place
+        dz_fused = false;
         if (i > 0) {
             if (l.kind == 0) {
+                rc = conv_dgrad_img(l, P.L[i - 1], x3, params, dz_cur, ws, B, st, &dz_fused);
+                if (rc) return rc;
+            }
+            if (dz_fused) {
+            } else if (l.kind == 0) {
                 const bool small = l.cin_p <= 32;
                 if (x3) rc = small ? launch_conv_dgrad<32, 3>(l, params, dz_cur, ws + P.da_off, B, st)
                                    : launch_conv_dgrad<64, 3>(l, params, dz_cur, ws + P.da_off, B, st);

@@ -34,6 +34,10 @@ struct Layer {
     int fwd_splits; // dense: split-K factor of the forward GEMM
     // conv: image-resident weight gradient (conv_img.h): 0 = use the generic engine
     int wgi_ntw, wgi_G, wgi_groups;
+    // conv (layer >= 1): image-resident data gradient with the LayerNorm backward of the layer below fused in
+    int dgi_tiles;       // workgroups per image (0 = generic engine + separate ln_bwd)
+    int64_t red_off;     // hidden layers: reduced (dgamma, dbeta, dbias) row [3][out_p]
+    int part_rows;       // rows of the partial-sum region
     char name[16];
     char ln_name[16];
 };
@@ -177,11 +181,23 @@ static inline int build_plan(const isdqn_net_config* cfg, Plan& P) {
     for (int i = 0; i < nl; ++i) {
         Layer& l = P.L[i];
         l.act_off = l.z_off = l.dz_off = l.part_off = -1;
+        l.dgi_tiles = 0;
+        if (l.kind == 0 && i > 0 && l.ksz % l.stride == 0 && l.cout_p <= 64 && l.cin_p <= 64) {
+            int tiles = 0;
+            for (int c = 0; c < l.stride * l.stride; ++c) {
+                int cy = c / l.stride, cx = c % l.stride;
+                int Ha = (l.hin - cy + l.stride - 1) / l.stride, Wb = (l.win - cx + l.stride - 1) / l.stride;
+                tiles += ceil_div(Ha * Wb, 128);
+            }
+            l.dgi_tiles = tiles;
+        }
         if (!l.is_head) {
             l.act_off = region(std::string("act/") + l.name, (int64_t)P.N2 * l.out_elems_p);
             l.z_off = region(std::string("z/") + l.name, (int64_t)P.B * l.out_elems_p);
             l.dz_off = region(std::string("dz/") + l.name, (int64_t)P.B * l.out_elems_p);
-            l.part_off = region(std::string("part/") + l.name, (int64_t)LN_MAX_BLOCKS * 3 * l.out_p);
+            l.part_rows = LN_MAX_BLOCKS;
+            l.part_off = -2;  // sized below, once the consumer layer's tiling is known
+            l.red_off = region(std::string("red/") + l.name, 3 * (int64_t)l.out_p);
         }
         if (i > 0 && (int64_t)P.B * l.in_elems_p > P.da_floats) P.da_floats = (int64_t)P.B * l.in_elems_p;
         // weight-gradient slabs: split the contraction (online pixels / batch rows) over workgroups
@@ -225,6 +241,13 @@ static inline int build_plan(const isdqn_net_config* cfg, Plan& P) {
             if (need > P.slab_floats) P.slab_floats = need;
         }
         l.gw_off = region(std::string("gw/") + l.name, (int64_t)l.gw_slabs * l.w_size);
+    }
+    for (int i = 0; i < nl; ++i) {
+        Layer& l = P.L[i];
+        if (l.is_head) continue;
+        if (i + 1 < nl && P.L[i + 1].dgi_tiles > 0 && P.B * P.L[i + 1].dgi_tiles > l.part_rows)
+            l.part_rows = P.B * P.L[i + 1].dgi_tiles;
+        l.part_off = region(std::string("part/") + l.name, (int64_t)l.part_rows * 3 * l.out_p);
     }
     P.q_off = region("q", (int64_t)P.N2 * P.nha_p);
     P.dout_off = region("dout", (int64_t)P.B * P.nha_p);
