@@ -31,7 +31,15 @@ __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict
         float v = 0.f;
         if (c < F) {
             const float* p = slabs + (int64_t)row * Fp + c;
-            for (int s = 0; s < n_slabs; ++s) v += p[(int64_t)s * slab_stride];
+            int s = 0;
+            for (; s + 8 <= n_slabs; s += 8) {  // 8 independent loads in flight, fixed summation order
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = p[(int64_t)(s + u) * slab_stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += t[u];
+            }
+            for (; s < n_slabs; ++s) v += p[(int64_t)s * slab_stride];
             v += bias[c];
         }
         s_row[c] = v;
@@ -571,6 +579,14 @@ static int plain_big(bool x3, const MatSrc& A, const float* A2, int a_split, con
                                                                  st);
 }
 
+// 128 x 64 tiles: twice the workgroups of plain_big for GEMMs whose 128 x 128 grid cannot fill 256 CUs
+template <bool ATR, bool BTR>
+static int plain_narrow(bool x3, const MatSrc& A, const MatSrc& B, float* C, int ldc, int M, int N, int K, int splits,
+                        int64_t slab_stride, hipStream_t st) {
+    if (x3) return launch_plain<128, 64, 2, 2, ATR, BTR, 3, true, false>(A, nullptr, 0, B, C, ldc, M, N, K, splits, slab_stride, st);
+    return launch_plain<128, 64, 2, 2, ATR, BTR, 1, true, false>(A, nullptr, 0, B, C, ldc, M, N, K, splits, slab_stride, st);
+}
+
 static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int rows,
                      int z_rows, float* slab, float* act, float* z, hipStream_t st) {
     MatSrc A, B;
@@ -899,6 +915,41 @@ extern "C" int isdqn_net_forward(const isdqn_net_config* cfg, const float* param
     return ISDQN_OK;
 }
 
+// Side stream for the weight gradients.  The backward's critical path is dgrad -> LayerNorm-backward -> dgrad ...;
+// every weight gradient only needs its layer's dz and is needed again by Adam at the very end, so they run on a
+// second HIP stream and share the CUs with the data-gradient chain (both sides are partly latency bound and
+// their workgroups co-reside).  One stream + event pool per device, created on first use, never destroyed.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2 * MAX_LAYERS + 4];
+    int n_ev = 0, next = 0;
+    bool ok = false;
+};
+static SideStream* side_stream() {
+    static SideStream per_dev[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream& s = per_dev[dev];
+    if (!s.ok) {
+        const char* e = getenv("ISDQN_SINGLE_STREAM");
+        if (e && atoi(e)) return nullptr;
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        s.n_ev = 2 * MAX_LAYERS + 4;
+        for (int i = 0; i < s.n_ev; ++i)
+            if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        s.ok = true;
+    }
+    return &s;
+}
+// make `waiter` wait for everything enqueued so far on `signaller`
+static int chain(SideStream* ss, hipStream_t signaller, hipStream_t waiter) {
+    hipEvent_t e = ss->ev[ss->next];
+    ss->next = (ss->next + 1) % ss->n_ev;
+    ISDQN_HIP_CHECK(hipEventRecord(e, signaller));
+    ISDQN_HIP_CHECK(hipStreamWaitEvent(waiter, e, 0));
+    return ISDQN_OK;
+}
+
 static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v, int32_t* adam_count,
                          const isdqn_batch* batch, float* losses, float* loss_accum, float* q_values, float* targets,
                          double* priorities, void* workspace, void* stream, bool learn, float* grad_out) {
@@ -952,6 +1003,8 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     const float* dz_cur = ws + P.dout_off;  // gradient w.r.t. the current layer's pre-activation output
     int dz_ld = P.nha_p;
     bool dz_fused = false;  // dz of layer i was already produced by the fused data gradient of layer i+1
+    SideStream* ss = side_stream();
+    hipStream_t wst = ss ? ss->stream : st;  // stream of the weight gradients
     for (int i = P.n_layers - 1; i >= 0; --i) {
         const Layer& l = P.L[i];
         const float* act_in = i > 0 ? ws + P.L[i - 1].act_off : nullptr;
@@ -979,6 +1032,10 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         } else {
             add_entry(l.b_off, l.out_p, ws + P.dbh_off, 1, 0);
         }
+        if (ss) {  // dz of this layer is final on the main stream: the weight-gradient stream may read it
+            rc = chain(ss, st, wst);
+            if (rc) return rc;
+        }
         // data gradient for the layer below first: it reads this layer's weights, which the fused-Adam
         // weight-gradient epilogue below updates in place
         dz_fused = false;
@@ -998,7 +1055,10 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 // da[b][in_p] = sum_o dz[b][o] * W[o][in_p]
                 MatSrc A{dz_cur, dz_ld, B, l.out_p, 1};
                 MatSrc Bm{params + l.w_off, l.in_p, l.out_f, l.in_p, 1};
-                rc = plain_big<false, true>(x3, A, nullptr, 0, Bm, ws + P.da_off, l.in_p, B, l.in_p, l.out_p, 1, 0, st);
+                if (ceil_div(B, 128) * ceil_div(l.in_p, 128) < 200)
+                    rc = plain_narrow<false, true>(x3, A, Bm, ws + P.da_off, l.in_p, B, l.in_p, l.out_p, 1, 0, st);
+                else
+                    rc = plain_big<false, true>(x3, A, nullptr, 0, Bm, ws + P.da_off, l.in_p, B, l.in_p, l.out_p, 1, 0, st);
             }
             if (rc) return rc;
         }
@@ -1007,15 +1067,15 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         bool fused_adam = false;
         if (l.kind == 0) {
             int img_slabs = 0;
-            rc = conv_wgrad_img(l, x3, in, act_in, dz_cur, ws + l.gw_off, B, st, &img_slabs);
+            rc = conv_wgrad_img(l, x3, in, act_in, dz_cur, ws + l.gw_off, B, wst, &img_slabs);
             if (rc) return rc;
             if (img_slabs) {
                 w_slabs = img_slabs;
             } else {
-            if (l.is_u8) rc = x3 ? launch_conv_wgrad<2, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, st)
-                                 : launch_conv_wgrad<1, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, st);
-            else rc = x3 ? launch_conv_wgrad<3, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, st)
-                         : launch_conv_wgrad<1, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, st);
+            if (l.is_u8) rc = x3 ? launch_conv_wgrad<2, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, wst)
+                                 : launch_conv_wgrad<1, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, wst);
+            else rc = x3 ? launch_conv_wgrad<3, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, wst)
+                         : launch_conv_wgrad<1, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, wst);
             w_slabs = conv_wgrad_slabs(l, B);
             }
         } else {
@@ -1026,25 +1086,33 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
             w_slabs = effective_splits(B, l.gw_slabs);
             if (w_slabs == 1 && !l.in_unpadded_ld) {
                 fused_adam = true;
+                if (ss && i > 0) {  // the in-place update must not overtake this layer's data gradient (reads W)
+                    rc = chain(ss, st, wst);
+                    if (rc) return rc;
+                }
                 AdamFuse af{params + l.w_off, adam_m + l.w_off, adam_v + l.w_off, ws + P.adam_tab_off,
                             cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps,
                             grad_out ? grad_out + l.w_off : nullptr};
                 rc = x3 ? launch_plain<128, 128, 2, 2, true, true, 3, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                         l.out_p, l.in_p, B, 1, 0, st, &af)
+                                                                                         l.out_p, l.in_p, B, 1, 0, wst, &af)
                         : launch_plain<128, 128, 2, 2, true, true, 1, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                         l.out_p, l.in_p, B, 1, 0, st, &af);
+                                                                                         l.out_p, l.in_p, B, 1, 0, wst, &af);
             } else {
                 rc = l.in_unpadded_ld
                          ? plain_big<true, true, false>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
-                                                        l.gw_slabs, l.w_size, st)
+                                                        l.gw_slabs, l.w_size, wst)
                          : plain_big<true, true>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
-                                                 l.gw_slabs, l.w_size, st);
+                                                 l.gw_slabs, l.w_size, wst);
             }
         }
         if (rc) return rc;
         if (!fused_adam) add_entry(l.w_off, l.w_size, ws + l.gw_off, w_slabs, l.w_size);
     }
     tab.total_blocks = blocks;
+    if (ss) {  // all weight gradients done before Adam (and before the next call touches the workspace)
+        rc = chain(ss, wst, st);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, tab, params, adam_m, adam_v, ws + P.adam_tab_off,
                        cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps, grad_out);
     ISDQN_HIP_CHECK(hipGetLastError());

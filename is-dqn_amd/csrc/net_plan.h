@@ -232,7 +232,7 @@ static inline int build_plan(const isdqn_net_config* cfg, Plan& P) {
             l.gw_slabs = s;
             // forward split-K slabs
             int ft = ceil_div(P.N2, 128) * ceil_div(l.out_p, 128);
-            int fs = ft >= 128 ? 1 : 256 / ft;
+            int fs = ft >= 256 ? 1 : 512 / ft;  // ~512 workgroups: two per CU hide each other's operand latency
             int fk = ceil_div(l.K, 32);
             if (fs > fk) fs = fk;
             if (fs < 1) fs = 1;
