@@ -394,24 +394,39 @@ struct AdamTable {
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* __restrict__ p, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ consts, float lr,
                                                    float b1, float b2, float eps, float* __restrict__ grad_out) {
+    // A workgroup covers 16 float4 positions; 16 "slab lanes" per position split the slab reduction (up to a
+    // few hundred split-K / per-image-group slabs for the conv kernels) and combine through LDS in a fixed
+    // order, so the reduction is deterministic and never a long serial chain of dependent loads.
+    __shared__ float4 s_g[16][16];
     int e = 0;
     while (e + 1 < tab.n && (int)blockIdx.x >= tab.e[e + 1].block_start) ++e;
     const AdamEntry en = tab.e[e];
     const float c1 = consts[0], c2 = consts[1];  // 1 - b1^t, 1 - b2^t (loss_finalize_kernel)
-    int64_t i = ((int64_t)(blockIdx.x - en.block_start) * 256 + threadIdx.x) * 4;
-    if (i >= en.size) return;
-    // slab reduction, 8 independent loads in flight per round (fixed order: deterministic)
+    const int pos = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int64_t i = ((int64_t)(blockIdx.x - en.block_start) * 16 + pos) * 4;
+    const bool on = i < en.size;
     float4 g = float4{0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 8 <= en.n_slabs; s += 8) {
-        float4 h[8];
+    if (on) {
+        int s = sl;
+        for (; s + 3 * 16 < en.n_slabs; s += 4 * 16) {
+            float4 h[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) h[u] = *reinterpret_cast<const float4*>(en.g + (int64_t)(s + u) * en.slab_stride + i);
+            for (int u = 0; u < 4; ++u) h[u] = *reinterpret_cast<const float4*>(en.g + (int64_t)(s + u * 16) * en.slab_stride + i);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { g.x += h[u].x; g.y += h[u].y; g.z += h[u].z; g.w += h[u].w; }
+            for (int u = 0; u < 4; ++u) { g.x += h[u].x; g.y += h[u].y; g.z += h[u].z; g.w += h[u].w; }
+        }
+        for (; s < en.n_slabs; s += 16) {
+            float4 h = *reinterpret_cast<const float4*>(en.g + (int64_t)s * en.slab_stride + i);
+            g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
+        }
     }
-    for (; s < en.n_slabs; ++s) {
-        float4 h = *reinterpret_cast<const float4*>(en.g + (int64_t)s * en.slab_stride + i);
+    s_g[sl][pos] = g;
+    __syncthreads();
+    if (sl != 0 || !on) return;
+    g = s_g[0][pos];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const float4 h = s_g[k][pos];
         g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
     }
     const int64_t o = en.p_off + i;
@@ -998,7 +1013,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         AdamEntry& e = tab.e[tab.n++];
         e.p_off = p_off; e.size = size; e.g = g; e.n_slabs = n_slabs; e.slab_stride = stride;
         e.block_start = blocks;
-        blocks += (int)((size + 1023) / 1024);
+        blocks += (int)((size + 63) / 64);
     };
     const float* dz_cur = ws + P.dout_off;  // gradient w.r.t. the current layer's pre-activation output
     int dz_ld = P.nha_p;
