@@ -1047,7 +1047,13 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         } else {
             add_entry(l.b_off, l.out_p, ws + P.dbh_off, 1, 0);
         }
-        if (ss) {  // dz of this layer is final on the main stream: the weight-gradient stream may read it
+        // Weight gradients of the middle layers go to the side stream.  Every fork costs the main stream an event
+        // record (a ~6 us bubble), so the head's tiny weight gradient and the first layer's (nothing is left to
+        // overlap with) stay on the main stream, and a layer whose Adam is fused forks once, after its data gradient.
+        const bool wg_on_side = ss && !l.is_head && i > 0;
+        hipStream_t lws = wg_on_side ? wst : st;
+        const bool fork_after_dgrad = wg_on_side && l.kind == 1;
+        if (wg_on_side && !fork_after_dgrad) {  // dz of this layer is final on the main stream
             rc = chain(ss, st, wst);
             if (rc) return rc;
         }
@@ -1078,19 +1084,23 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
             if (rc) return rc;
         }
         // weight gradient -> slabs (or straight into Adam when one workgroup holds the whole contraction)
+        if (fork_after_dgrad) {  // dz is final AND the data gradient (which reads W) is enqueued: an in-place
+            rc = chain(ss, st, wst);  // fused-Adam update on the side stream cannot overtake it
+            if (rc) return rc;
+        }
         int w_slabs;
         bool fused_adam = false;
         if (l.kind == 0) {
             int img_slabs = 0;
-            rc = conv_wgrad_img(l, x3, in, act_in, dz_cur, ws + l.gw_off, B, wst, &img_slabs);
+            rc = conv_wgrad_img(l, x3, in, act_in, dz_cur, ws + l.gw_off, B, lws, &img_slabs);
             if (rc) return rc;
             if (img_slabs) {
                 w_slabs = img_slabs;
             } else {
-            if (l.is_u8) rc = x3 ? launch_conv_wgrad<2, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, wst)
-                                 : launch_conv_wgrad<1, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, wst);
-            else rc = x3 ? launch_conv_wgrad<3, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, wst)
-                         : launch_conv_wgrad<1, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, wst);
+            if (l.is_u8) rc = x3 ? launch_conv_wgrad<2, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws)
+                                 : launch_conv_wgrad<1, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws);
+            else rc = x3 ? launch_conv_wgrad<3, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws)
+                         : launch_conv_wgrad<1, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws);
             w_slabs = conv_wgrad_slabs(l, B);
             }
         } else {
@@ -1101,23 +1111,20 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
             w_slabs = effective_splits(B, l.gw_slabs);
             if (w_slabs == 1 && !l.in_unpadded_ld) {
                 fused_adam = true;
-                if (ss && i > 0) {  // the in-place update must not overtake this layer's data gradient (reads W)
-                    rc = chain(ss, st, wst);
-                    if (rc) return rc;
-                }
+
                 AdamFuse af{params + l.w_off, adam_m + l.w_off, adam_v + l.w_off, ws + P.adam_tab_off,
                             cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps,
                             grad_out ? grad_out + l.w_off : nullptr};
                 rc = x3 ? launch_plain<128, 128, 2, 2, true, true, 3, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                         l.out_p, l.in_p, B, 1, 0, wst, &af)
+                                                                                         l.out_p, l.in_p, B, 1, 0, lws, &af)
                         : launch_plain<128, 128, 2, 2, true, true, 1, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                         l.out_p, l.in_p, B, 1, 0, wst, &af);
+                                                                                         l.out_p, l.in_p, B, 1, 0, lws, &af);
             } else {
                 rc = l.in_unpadded_ld
                          ? plain_big<true, true, false>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
-                                                        l.gw_slabs, l.w_size, wst)
+                                                        l.gw_slabs, l.w_size, lws)
                          : plain_big<true, true>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
-                                                 l.gw_slabs, l.w_size, wst);
+                                                 l.gw_slabs, l.w_size, lws);
             }
         }
         if (rc) return rc;

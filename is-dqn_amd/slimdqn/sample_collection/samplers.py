@@ -66,6 +66,8 @@ class UniformSamplingDistribution:
         self._index_to_key = []
         self.device = torch.device(device)
         self._uploader = None
+        self._pf = None        # prefetched draws: dict(host, dev, next, n, size, length, state)
+        self._last_len = -1
 
     # -- bookkeeping -----------------------------------------------------------------------------
     def add(self, key) -> None:
@@ -95,10 +97,37 @@ class UniformSamplingDistribution:
         assert self._index_to_key, ValueError("No keys to sample from.")
         return self._rng_key.integers(len(self._index_to_key), size=size)
 
+    # Draws are produced PREFETCH batches at a time once the number of keys has stopped changing (a full
+    # FIFO buffer): n consecutive ``integers(len, size)`` calls are exactly what n reference ``sample`` calls
+    # consume, so one upload serves n steps.  If the length changes while pre-drawn batches are unused, the
+    # generator is rewound to the state before the block and advanced by the batches actually consumed --
+    # the stream position is always the reference's.
+    PREFETCH = 64
+
+    def _next_row(self, size: int):
+        length = len(self._index_to_key)
+        assert length, ValueError("No keys to sample from.")
+        pf = self._pf
+        if pf is not None and (pf["size"] != size or pf["length"] != length or pf["next"] >= pf["n"]):
+            if pf["next"] < pf["n"]:
+                self._rng_key.bit_generator.state = pf["state"]
+                for _ in range(pf["next"]):
+                    self._rng_key.integers(pf["length"], size=pf["size"])
+            pf = self._pf = None
+        if pf is None:
+            n = self.PREFETCH if self._last_len == length else 1
+            self._last_len = length
+            state = self._rng_key.bit_generator.state
+            host = np.stack([self._rng_key.integers(length, size=size) for _ in range(n)]).astype(np.int32)
+            pf = self._pf = dict(host=host, dev=None, next=0, n=n, size=size, length=length, state=state)
+        k = pf["next"]
+        pf["next"] = k + 1
+        return pf, k
+
     def sample(self, size: int):
-        indices = self._draw_indices(size)
+        pf, k = self._next_row(size)
         i2k = self._index_to_key
-        return np.fromiter((i2k[i] for i in indices), dtype=np.int32, count=size)
+        return np.fromiter((i2k[i] for i in pf["host"][k]), dtype=np.int32, count=size)
 
     def _to_device(self, host: np.ndarray, dtype) -> torch.Tensor:
         if self.device.type != "cuda":
@@ -110,7 +139,10 @@ class UniformSamplingDistribution:
 
     def sample_device(self, size: int) -> torch.Tensor:
         """Dense indices on the device (int32); the draw is the reference's ``integers(len, size)``."""
-        return self._to_device(self._draw_indices(size).astype(np.int32), torch.int32)
+        pf, k = self._next_row(size)
+        if pf["dev"] is None:
+            pf["dev"] = self._to_device(pf["host"], torch.int32)
+        return pf["dev"][k]
 
     def keys_of(self, indices: np.ndarray) -> np.ndarray:
         i2k = self._index_to_key
@@ -183,6 +215,17 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         return self.keys_of(indices)
 
     def sample_device(self, size: int) -> torch.Tensor:
-        unit = self._rng_key.random(size)  # uniform(0, root, size) == 0.0 + root * random(size)
-        u = self._to_device(unit, torch.float64)
-        return self._sum_tree.query_device(u, unit=True)
+        # uniform(0, root, size) == 0.0 + root * random(size): the unit draws depend on neither the root nor the
+        # number of keys, so PREFETCH batches are drawn and uploaded at once; the root is applied on the device
+        pu = getattr(self, "_pu", None)
+        if pu is None or pu["size"] != size or pu["next"] >= self.PREFETCH:
+            if pu is not None and pu["next"] < self.PREFETCH:  # batch size changed mid-block: rewind, replay consumed
+                self._rng_key.bit_generator.state = pu["state"]
+                for _ in range(pu["next"]):
+                    self._rng_key.random(pu["size"])
+            state = self._rng_key.bit_generator.state
+            host = np.stack([self._rng_key.random(size) for _ in range(self.PREFETCH)])
+            pu = self._pu = dict(dev=self._to_device(host, torch.float64), next=0, size=size, state=state)
+        k = pu["next"]
+        pu["next"] = k + 1
+        return self._sum_tree.query_device(pu["dev"][k], unit=True)

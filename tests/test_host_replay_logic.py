@@ -94,3 +94,38 @@ def test_uniform_sampler_host_stream_matches_oracle():
     assert a._index_to_key == b._index_to_key
     with pytest.raises(AssertionError):
         a.remove(0)
+
+
+def test_prefetched_draws_stay_on_the_reference_stream():
+    """sample_device pre-draws 64 batches once the key count is stable; when the count changes with unused
+    batches left, the generator is rewound and re-advanced -- every batch must equal the oracle's (= the
+    reference's one ``integers(len, size)`` call per sample)."""
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+
+    a, b = UniformSamplingDistribution(11, device="cpu"), OracleUniform(11)
+    for k in range(50):
+        a.add(k)
+        b.add(k)
+    nxt = 50
+    rng = np.random.default_rng(0)
+    for step in range(400):
+        if step % 2 == 0:
+            got = np.asarray([a._index_to_key[i] for i in a.sample_device(16).numpy()], dtype=np.int32)
+        else:
+            got = a.sample(16)
+        np.testing.assert_array_equal(got, b.sample(16))
+        r = rng.random()
+        if r < 0.05:  # grow
+            a.add(nxt)
+            b.add(nxt)
+            nxt += 1
+        elif r < 0.10:  # FIFO-style replace: length unchanged
+            a.add(nxt)
+            b.add(nxt)
+            victim = a._index_to_key[0]
+            a.remove(victim)
+            b.remove(victim)
+            nxt += 1
+        elif r < 0.12:  # different batch size once in a while
+            np.testing.assert_array_equal(a.sample(5), b.sample(5))
+    assert a._pf is not None and a._pf["n"] in (1, 64)
