@@ -200,6 +200,7 @@ def main():
     for i in range(args.steps):
         rep.step()
     ev1.record()
+    t_issue = time.perf_counter() - t0  # host time to enqueue the region (== elapsed when the host is the bottleneck)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -234,6 +235,7 @@ def main():
                 "traffic": None,
                 "kernel": "replay-sample -> Bellman-update step (all launches of one step; HIP-event time per step)",
                 "algorithmic_bytes_per_step": bytes_step, "device_ms_per_step_avg": dev_ms_avg,
+                "host_issue_ms_per_step": t_issue / args.steps * 1e3,
                 "mfma_util_vs_2.5PF": flops_step / (dev_ms_avg * 1e-3) / 2.5e15,
             },
         }

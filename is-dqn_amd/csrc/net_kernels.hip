@@ -912,9 +912,10 @@ static int check_input(const isdqn_net_config* cfg, const uint8_t* frames, int64
 extern "C" int isdqn_net_forward(const isdqn_net_config* cfg, const float* params, const uint8_t* frames,
                                  int64_t frame_stride, const int32_t* frame_ids, const float* obs, int32_t n_rows,
                                  float* q_out, void* workspace, void* stream) {
-    Plan P;
-    int rc = build_plan(cfg, P);
-    if (rc) return rc;
+    int rc;
+    const Plan* Pp = cached_plan(cfg, &rc);
+    if (!Pp) return rc;
+    const Plan& P = *Pp;
     ISDQN_REQUIRE(params && q_out && workspace, ISDQN_ERR_ARG, "null pointer");
     ISDQN_REQUIRE(n_rows >= 1 && n_rows <= P.N2, ISDQN_ERR_SHAPE, "n_rows must be in [1, 2*batch_size]");
     rc = check_input(cfg, frames, frame_stride, frame_ids, obs);
@@ -968,9 +969,10 @@ static int chain(SideStream* ss, hipStream_t signaller, hipStream_t waiter) {
 static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v, int32_t* adam_count,
                          const isdqn_batch* batch, float* losses, float* loss_accum, float* q_values, float* targets,
                          double* priorities, void* workspace, void* stream, bool learn, float* grad_out) {
-    Plan P;
-    int rc = build_plan(cfg, P);
-    if (rc) return rc;
+    int rc;
+    const Plan* Pp = cached_plan(cfg, &rc);
+    if (!Pp) return rc;
+    const Plan& P = *Pp;
     ISDQN_REQUIRE(params && batch && losses && workspace, ISDQN_ERR_ARG, "null pointer");
     ISDQN_REQUIRE(batch->B == P.B, ISDQN_ERR_SHAPE, "batch->B != cfg->batch_size");
     ISDQN_REQUIRE(batch->action && batch->reward && batch->terminal, ISDQN_ERR_ARG, "null batch field");
@@ -1179,9 +1181,10 @@ extern "C" int isdqn_net_shift_params(const isdqn_net_config* cfg, float* params
 extern "C" int isdqn_net_best_action(const isdqn_net_config* cfg, const float* params, const uint8_t* frames,
                                      int64_t frame_stride, const int32_t* frame_ids, const float* obs,
                                      int32_t idx_network, int32_t* out_action, void* workspace, void* stream) {
-    Plan P;
-    int rc = build_plan(cfg, P);
-    if (rc) return rc;
+    int rc;
+    const Plan* Pp = cached_plan(cfg, &rc);
+    if (!Pp) return rc;
+    const Plan& P = *Pp;
     ISDQN_REQUIRE(params && out_action && workspace, ISDQN_ERR_ARG, "null pointer");
     ISDQN_REQUIRE(idx_network >= 0 && idx_network < P.n_heads - 1, ISDQN_ERR_ARG, "idx_network out of range");
     rc = check_input(cfg, frames, frame_stride, frame_ids, obs);

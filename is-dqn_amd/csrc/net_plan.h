@@ -62,7 +62,7 @@ static inline void same_padding(int size, int k, int s, int& out, int& lo) {
     lo = total / 2;
 }
 
-static inline int build_plan(const isdqn_net_config* cfg, Plan& P) {
+static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
     ISDQN_REQUIRE(cfg != nullptr, ISDQN_ERR_ARG, "null config");
     ISDQN_REQUIRE(cfg->arch == ISDQN_ARCH_CNN || cfg->arch == ISDQN_ARCH_FC, ISDQN_ERR_UNSUPPORTED,
                   "architecture_type must be cnn or fc (impala is outside the hot-path scope)");
@@ -261,5 +261,27 @@ static inline int build_plan(const isdqn_net_config* cfg, Plan& P) {
     P.ws_bytes = off * 4;
     return ISDQN_OK;
 }
+
+// The plan of a configuration never changes: cache the last few (a training process uses one or two
+// configurations; building the plan allocates strings/vectors, which showed up in the per-step host time).
+static inline const Plan* cached_plan(const isdqn_net_config* cfg, int* rc_out) {
+    struct Slot { isdqn_net_config cfg; Plan plan; bool used = false; };
+    static thread_local Slot slots[4];
+    static thread_local int next = 0;
+    *rc_out = ISDQN_OK;
+    if (cfg == nullptr) { *rc_out = ISDQN_ERR_ARG; set_last_error("null config"); return nullptr; }
+    for (auto& s : slots)
+        if (s.used && memcmp(&s.cfg, cfg, sizeof(*cfg)) == 0) return &s.plan;
+    Slot& s = slots[next];
+    next = (next + 1) % 4;
+    s.used = false;
+    int rc = build_plan_uncached(cfg, s.plan);
+    if (rc) { *rc_out = rc; return nullptr; }
+    memcpy(&s.cfg, cfg, sizeof(*cfg));
+    s.used = true;
+    return &s.plan;
+}
+
+static inline int build_plan(const isdqn_net_config* cfg, Plan& P) { return build_plan_uncached(cfg, P); }
 
 }  // namespace isdqn

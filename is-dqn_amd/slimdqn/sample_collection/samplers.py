@@ -25,7 +25,8 @@ class _Uploader:
     pinned buffers on a side stream, so that the copy engine moves them while the previous steps still compute;
     the consuming stream only waits on an event.  (A pageable copy costs a ~25 us blit kernel in the step.)"""
 
-    SLOTS = 32
+    SLOTS = 4        # pinning host memory costs ~30 ms per buffer: a few slots, allocated once, reused forever
+    SLOT_BYTES = 1 << 18
 
     def __init__(self, device):
         self.device = device
@@ -42,7 +43,7 @@ class _Uploader:
             self.events[k].synchronize()  # the slot's previous copy has long finished; never races the host write
         n = host.nbytes
         if self.pinned[k] is None or self.pinned[k].numel() < n:
-            self.pinned[k] = torch.empty(max(n, 8192), dtype=torch.uint8).pin_memory()
+            self.pinned[k] = torch.empty(max(n, self.SLOT_BYTES), dtype=torch.uint8).pin_memory()
         src = torch.from_numpy(host)
         view = self.pinned[k][:n].view(src.dtype).view(src.shape)
         view.copy_(src)
