@@ -80,6 +80,12 @@ class Replica:
                               device=device)
         self.eng.init_params(seed)
         torch.cuda.synchronize()
+        self.graphed = None
+
+    def enable_graph(self, steps_per_graph):
+        from slimdqn._graph import GraphedUpdate
+
+        self.graphed = GraphedUpdate(self.rb, self.eng, self.w["prioritized"], steps_per_graph)
 
     def step(self):
         batch = self.rb.sample()
@@ -164,6 +170,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--capacity", type=int, default=1_000_000)
+    ap.add_argument("--graph", type=int, default=8, help="steps captured per hipGraph (0 = eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -185,8 +192,19 @@ def main():
     w = WORKLOADS[args.workload]
 
     rep = Replica(args.workload, args.capacity, args.precision, seed=rank, device=device)
-    for _ in range(args.warmup):
-        rep.step()
+    S = 1
+    if args.graph > 0:
+        try:
+            rep.enable_graph(args.graph)
+            S = args.graph
+        except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+            rep.graphed = None
+    args.steps = max(S, args.steps // S * S)  # a graph replays S steps at a time
+    args.warmup = max(S, args.warmup // S * S)
+    one = (lambda: rep.graphed.run()) if rep.graphed is not None else rep.step
+    for _ in range(args.warmup // S):
+        one()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -197,8 +215,8 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for i in range(args.steps):
-        rep.step()
+    for i in range(args.steps // S):
+        one()
     ev1.record()
     t_issue = time.perf_counter() - t0  # host time to enqueue the region (== elapsed when the host is the bottleneck)
     torch.cuda.synchronize()
@@ -229,7 +247,7 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": w["desc"], "replay_capacity": args.capacity, "precision": args.precision,
-                       "replicas": world, "parallelism": f"independent-seed replicas x{world}"},
+                       "launch": f"hipGraph x{S} steps" if rep.graphed is not None else "eager", "replicas": world, "parallelism": f"independent-seed replicas x{world}"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,

@@ -96,12 +96,25 @@ __global__ __launch_bounds__(TREE_SET_THREADS) void tree_set_kernel(double* __re
             int nd = ancestor(u_node[i], level);
             int prev = i > 0 ? ancestor(u_node[i - 1], level) : -1;
             if (nd != prev) {
+                // the run of leaves below `nd` is u_node in [first_below, last_below]: find its end by binary
+                // search (u_node is sorted), then add the deltas strictly left to right (np.add.at order)
+                const long long limit = ((long long)(nd + 2) << level) - 1;  // first node index NOT below nd
+                int lo = i + 1, hi = m;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if ((long long)u_node[mid] < limit) lo = mid + 1; else hi = mid;
+                }
+                const int end = lo;
                 double acc = nodes[nd];
                 int j = i;
-                do {
-                    acc = acc + u_delta[j];
-                    ++j;
-                } while (j < m && ancestor(u_node[j], level) == nd);
+                for (; j + 4 <= end; j += 4) {
+                    const double d0 = u_delta[j], d1 = u_delta[j + 1], d2 = u_delta[j + 2], d3 = u_delta[j + 3];
+                    acc = acc + d0;
+                    acc = acc + d1;
+                    acc = acc + d2;
+                    acc = acc + d3;
+                }
+                for (; j < end; ++j) acc = acc + u_delta[j];
                 nodes[nd] = acc;
             }
         }

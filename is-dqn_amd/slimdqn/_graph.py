@@ -1,0 +1,90 @@
+"""hipGraph capture of the replay-sample -> Bellman-update step.
+
+One step is ~30 kernel launches on two HIP streams; launched eagerly the host spends ~380 us per step on
+launch API calls, about as long as the GPU needs to run them.  ``GraphedUpdate`` captures `S` consecutive
+steps (index row -> [sum-tree query] -> row gather -> learn_on_batch -> [priority write-back]) once, with
+static buffers, and replays them: one graph launch per S steps.
+
+The draws stay on the host (numpy PCG64, the reference's stream): before a replay the next S rows of
+pre-drawn dense indices (uniform) or unit draws (prioritized) are copied into the static input block.
+"""
+from __future__ import annotations
+
+import torch
+
+from slimdqn import _hip
+
+
+class GraphedUpdate:
+    def __init__(self, rb, eng, prioritized: bool, steps_per_graph: int = 8):
+        self.rb, self.eng, self.prioritized, self.S = rb, eng, prioritized, steps_per_graph
+        dev, B, s2 = eng.device, eng.batch_size, 2 * rb._stack_size
+        self.B = B
+        rb._flush()
+        self.block = torch.zeros(self.S, B, dtype=torch.float64 if prioritized else torch.int32, device=dev)
+        self.indices = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.frame_ids = torch.zeros(B, s2, dtype=torch.int32, device=dev)
+        self.action = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.reward = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.terminal = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self._frames_ptr = rb._frames.data_ptr()
+        self.batch = eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids,
+                                    action=self.action, reward=self.reward, terminal=self.terminal)
+        self.graph = None
+        self._capture()
+
+    def _one(self, s: int) -> None:
+        rb, eng = self.rb, self.eng
+        if self.prioritized:
+            tree = rb._sampling_distribution._sum_tree
+            tree.query_device(self.block[s], out=self.indices, unit=True)
+            idx = self.indices
+        else:
+            idx = self.block[s]
+        _hip.check(
+            rb._lib.isdqn_replay_gather_rows(
+                _hip.ptr(rb._d_elem_frames), _hip.ptr(rb._d_elem_action), _hip.ptr(rb._d_elem_reward),
+                _hip.ptr(rb._d_elem_terminal), rb._stack_size, _hip.ptr(rb._d_index_to_slot), _hip.ptr(idx), self.B,
+                _hip.ptr(self.frame_ids), _hip.ptr(self.action), _hip.ptr(self.reward), _hip.ptr(self.terminal),
+                _hip.stream_ptr(),
+            ),
+            "isdqn_replay_gather_rows",
+        )
+        eng.learn_on_batch(self.batch)
+        if self.prioritized:
+            rb._sampling_distribution.update_device(idx, eng.priorities)
+
+    def _capture(self) -> None:
+        # warm-up on a side stream (lazy one-time setup inside the library must not happen during capture)
+        side = torch.cuda.Stream(self.eng.device)
+        side.wait_stream(torch.cuda.current_stream(self.eng.device))
+        state = [t.clone() for t in (self.eng.params, self.eng.adam_m, self.eng.adam_v, self.eng.adam_count, self.eng.losses_accum)]
+        tree_nodes = self.rb._sampling_distribution._sum_tree._nodes_dev.clone() if self.prioritized else None
+        with torch.cuda.stream(side):
+            self._one(0)
+        torch.cuda.current_stream(self.eng.device).wait_stream(side)
+        torch.cuda.synchronize(self.eng.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for s in range(self.S):
+                self._one(s)
+        # the warm-up step must not count: restore the training state
+        for dst, src in zip((self.eng.params, self.eng.adam_m, self.eng.adam_v, self.eng.adam_count, self.eng.losses_accum), state):
+            dst.copy_(src)
+        if tree_nodes is not None:
+            self.rb._sampling_distribution._sum_tree._nodes_dev.copy_(tree_nodes)
+        self.graph = g
+
+    def run(self) -> None:
+        """S steps: draw S index rows on the host stream of the sampler, stage them, replay the graph."""
+        rb = self.rb
+        rb._flush()
+        if rb._frames.data_ptr() != self._frames_ptr:  # the frame store was re-allocated: pointers in the graph are stale
+            self._frames_ptr = rb._frames.data_ptr()
+            self.batch = self.eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids,
+                                             action=self.action, reward=self.reward, terminal=self.terminal)
+            self._capture()
+        sampler = rb._sampling_distribution
+        rows = sampler.draw_rows_device(self.S, self.B)
+        self.block.copy_(rows, non_blocking=True)
+        self.graph.replay()

@@ -145,6 +145,18 @@ class UniformSamplingDistribution:
             pf["dev"] = self._to_device(pf["host"], torch.int32)
         return pf["dev"][k]
 
+    def draw_rows_device(self, n: int, size: int) -> torch.Tensor:
+        """The next ``n`` batches of dense indices as one [n, size] device tensor (graph-replayed steps);
+        exactly the draws n ``sample_device(size)`` calls would make."""
+        rows = [self.sample_device(size) for _ in range(n)]
+        first = rows[0]
+        # rows of one prefetched block are consecutive views of the same tensor: hand out the slab without a copy
+        base = first.untyped_storage().data_ptr()
+        if all(r.untyped_storage().data_ptr() == base and r.storage_offset() == first.storage_offset() + i * size
+               for i, r in enumerate(rows)):
+            return torch.as_strided(first, (n, size), (size, 1), first.storage_offset())
+        return torch.stack(rows)
+
     def keys_of(self, indices: np.ndarray) -> np.ndarray:
         i2k = self._index_to_key
         return np.fromiter((i2k[i] for i in indices), dtype=np.int32, count=len(indices))
@@ -230,3 +242,27 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         k = pu["next"]
         pu["next"] = k + 1
         return self._sum_tree.query_device(pu["dev"][k], unit=True)
+
+    def _next_units(self, size: int) -> torch.Tensor:
+        pu = getattr(self, "_pu", None)
+        if pu is None or pu["size"] != size or pu["next"] >= self.PREFETCH:
+            if pu is not None and pu["next"] < self.PREFETCH:
+                self._rng_key.bit_generator.state = pu["state"]
+                for _ in range(pu["next"]):
+                    self._rng_key.random(pu["size"])
+            state = self._rng_key.bit_generator.state
+            host = np.stack([self._rng_key.random(size) for _ in range(self.PREFETCH)])
+            pu = self._pu = dict(dev=self._to_device(host, torch.float64), next=0, size=size, state=state)
+        k = pu["next"]
+        pu["next"] = k + 1
+        return pu["dev"][k]
+
+    def draw_rows_device(self, n: int, size: int) -> torch.Tensor:
+        """The next ``n`` batches of UNIT draws ([n, size] float64): the graph applies the root on the device."""
+        rows = [self._next_units(size) for _ in range(n)]
+        first = rows[0]
+        base = first.untyped_storage().data_ptr()
+        if all(r.untyped_storage().data_ptr() == base and r.storage_offset() == first.storage_offset() + i * size
+               for i, r in enumerate(rows)):
+            return torch.as_strided(first, (n, size), (size, 1), first.storage_offset())
+        return torch.stack(rows)
