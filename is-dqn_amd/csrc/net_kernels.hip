@@ -1067,6 +1067,30 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 rc = conv_dgrad_img(l, P.L[i - 1], x3, params, dz_cur, ws, B, st, &dz_fused);
                 if (rc) return rc;
             }
+            if (l.kind == 1 && P.L[i - 1].kind == 0 && P.L[i - 1].cout_p == 64 && !l.in_unpadded_ld &&
+                P.L[i - 1].part_rows >= ceil_div(B, 128) * P.L[i - 1].npix) {
+                // first dense layer over a 64-channel conv output: data gradient + LN/ReLU backward in one kernel
+                const Layer& below = P.L[i - 1];
+                auto launch = [&](auto prob) {
+                    prob.A = MatSrc{dz_cur, dz_ld, B, l.out_p, 1};
+                    prob.B = MatSrc{params + l.w_off, l.in_p, l.out_f, l.in_p, 1};
+                    prob.z = ws + below.z_off;
+                    prob.gamma = below.has_ln ? params + below.g_off : nullptr;
+                    prob.beta = below.has_ln ? params + below.be_off : nullptr;
+                    prob.dz_out = ws + below.dz_off;
+                    prob.part = ws + below.part_off;
+                    prob.ldc = l.in_p; prob.M = B; prob.N = l.in_p; prob.K = l.out_p; prob.c_in = below.out_f;
+                    prob.tiles_m = ceil_div(B, 128); prob.tiles_n = l.in_p / 64;
+                    return launch_gemm(prob, prob.tiles_m * prob.tiles_n, st);
+                };
+                rc = x3 ? launch(DenseDgradLN<3>{}) : launch(DenseDgradLN<1>{});
+                if (rc) return rc;
+                const int width = 3 * below.out_p;
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(width, 8)), dim3(256), 0, st, ws + below.part_off,
+                                   ceil_div(B, 128) * (l.in_p / 64), width, ws + below.red_off);
+                ISDQN_HIP_CHECK(hipGetLastError());
+                dz_fused = true;
+            }
             if (dz_fused) {
             } else if (l.kind == 0) {
                 const bool small = l.cin_p <= 32;

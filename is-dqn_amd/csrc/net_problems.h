@@ -178,6 +178,137 @@ struct PlainGemm {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Data gradient of the first dense layer fused with the LayerNorm + ReLU backward of the conv layer below.
+//   da[b][pix*64 + c] = sum_o dz[b][o] * W[o][pix*64 + c]          (A = dz ROW, B = W TR)
+// A 128 x 64 tile is 128 samples x the 64 channels of ONE pixel, and with 4 waves stacked along M every wave holds
+// complete channel rows: the LayerNorm statistics of a row are 4 in-lane values + a 16-lane shuffle.  The epilogue
+// reads z of the conv output, writes dz of the conv layer directly (da never goes to HBM) and emits the
+// workgroup's partial sums of (dgamma, dbeta, dbias).
+// ---------------------------------------------------------------------------------------------
+template <int PASSES_>
+struct DenseDgradLN {
+    static constexpr int BM = 128, BN = 64, WM = 4, WN = 1, PASSES = PASSES_;
+    static constexpr bool A_TR = false, B_TR = true;
+    static constexpr int EPI_LDS_BYTES = 4 * 3 * 64 * 4;
+    MatSrc A, B;
+    const float* z;            // [M][ldc] pre-LayerNorm conv output (flat [b][pix][64])
+    const float *gamma, *beta; // nullptr: ReLU only
+    float* dz_out;             // [M][ldc]
+    float* part;               // [n_workgroups][3][64]
+    int ldc, M, N, K, c_in;
+    int tiles_m, tiles_n;
+    struct Tile { int m0, n0, k0, k1, wg; };
+    struct ACtx { int fixed; };
+    struct BCtx { int fixed; };
+    __device__ __forceinline__ bool tile(int bid, Tile& t) const {
+        t.wg = bid;
+        bid = xcd_remap(bid, tiles_m * tiles_n);
+        t.m0 = (bid % tiles_m) * BM;
+        t.n0 = (bid / tiles_m) * BN;
+        t.k0 = 0; t.k1 = K;
+        return bid < tiles_m * tiles_n;
+    }
+    __device__ __forceinline__ ACtx a_ctx(const Tile&, int fixed) const { return ACtx{fixed}; }
+    __device__ __forceinline__ BCtx b_ctx(const Tile&, int fixed) const { return BCtx{fixed}; }
+    __device__ __forceinline__ void load_a(const Tile&, const ACtx& c, int var, float (&v)[8]) const { A.load(c.fixed, var, v); }
+    __device__ __forceinline__ void load_b(const Tile&, const BCtx& c, int var, float (&v)[8]) const { B.load(var, c.fixed, v); }
+    template <int MT, int NT>
+    __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane, char* smem) const {
+        static_assert(NT == 4, "one wave must hold all 64 channels of a row");
+        const int grp = lane >> 4, li = lane & 15, wave = (m_wave - t.m0) / (MT * 16);
+        float ga[NT], be[NT], dg[NT], db[NT], dbias[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ch = nt * 16 + li;
+            const bool ok = ch < c_in;
+            ga[nt] = (ok && gamma) ? gamma[ch] : 1.f;
+            be[nt] = (ok && gamma) ? beta[ch] : 0.f;
+            dg[nt] = db[nt] = dbias[nt] = 0.f;
+        }
+        const float inv_c = 1.f / (float)c_in;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m_wave + mt * 16 + grp * 4 + r;
+                const bool row_ok = row < M;
+                const int64_t base = (int64_t)(row_ok ? row : 0) * ldc + t.n0;
+                float zv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) zv[nt] = z[base + nt * 16 + li];
+                float out[NT];
+                if (gamma != nullptr) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bool ok = (nt * 16 + li) < c_in;
+                        s1 += ok ? zv[nt] : 0.f;
+                        s2 += ok ? zv[nt] * zv[nt] : 0.f;
+                    }
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+                    const float mean = s1 * inv_c;
+                    const float rstd = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + 1e-6f);
+                    float xh[NT], gg[NT], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bool ok = row_ok && (nt * 16 + li) < c_in;
+                        xh[nt] = (zv[nt] - mean) * rstd;
+                        const float y = xh[nt] * ga[nt] + be[nt];
+                        const float dy = (ok && y > 0.f) ? acc[mt][nt][r] : 0.f;
+                        dg[nt] += dy * xh[nt];
+                        db[nt] += dy;
+                        gg[nt] = dy * ga[nt];
+                        m1 += gg[nt];
+                        m2 += gg[nt] * xh[nt];
+                    }
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) { m1 += __shfl_xor(m1, off); m2 += __shfl_xor(m2, off); }
+                    m1 *= inv_c;
+                    m2 *= inv_c;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bool ok = row_ok && (nt * 16 + li) < c_in;
+                        out[nt] = ok ? rstd * (gg[nt] - m1 - xh[nt] * m2) : 0.f;
+                        dbias[nt] += out[nt];
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bool ok = row_ok && (nt * 16 + li) < c_in;
+                        out[nt] = (ok && zv[nt] > 0.f) ? acc[mt][nt][r] : 0.f;
+                        dbias[nt] += out[nt];
+                    }
+                }
+                if (row_ok) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) dz_out[base + nt * 16 + li] = out[nt];
+                }
+            }
+        // partial sums: over the 4 row groups of the wave, then over the 4 waves (fixed order)
+        float* sp = reinterpret_cast<float*>(smem);  // [4 waves][3][64]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            dg[nt] += __shfl_xor(dg[nt], 16); dg[nt] += __shfl_xor(dg[nt], 32);
+            db[nt] += __shfl_xor(db[nt], 16); db[nt] += __shfl_xor(db[nt], 32);
+            dbias[nt] += __shfl_xor(dbias[nt], 16); dbias[nt] += __shfl_xor(dbias[nt], 32);
+            if (grp == 0) {
+                sp[(wave * 3 + 0) * 64 + nt * 16 + li] = dg[nt];
+                sp[(wave * 3 + 1) * 64 + nt * 16 + li] = db[nt];
+                sp[(wave * 3 + 2) * 64 + nt * 16 + li] = dbias[nt];
+            }
+        }
+        __syncthreads();
+        const int tid = threadIdx.x;
+        if (tid < 3 * 64) {
+            const int which = tid / 64, c = tid % 64;
+            part[((int64_t)t.wg * 3 + which) * 64 + c] =
+                sp[(0 * 3 + which) * 64 + c] + sp[(1 * 3 + which) * 64 + c] + sp[(2 * 3 + which) * 64 + c] + sp[(3 * 3 + which) * 64 + c];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Convolution geometry shared by the conv problems
 // ---------------------------------------------------------------------------------------------
 struct ConvGeom {
