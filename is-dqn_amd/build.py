@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libisdqn_hip.so")
 SOURCES = ["api.hip", "tree_kernels.hip", "replay_kernels.hip", "net_kernels.hip"]
-HEADERS = ["common.h", "gemm_core.h", "net_plan.h", "net_problems.h", os.path.join("..", "..", "include", "isdqn_hip.h")]
+HEADERS = sorted(f for f in os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")) if f.endswith(".h")) + [
+    os.path.join("..", "..", "include", "isdqn_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-ffp-contract=off"]
 
 

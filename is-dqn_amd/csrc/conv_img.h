@@ -29,7 +29,8 @@ struct ConvImgParams {
     int R, Wp;               // local rows / padded width of the LDS image
     int PP;                  // fp32 layers: pixel pitch in elements (cin_p + pad: spreads consecutive pixels over LDS banks)
     int plane_elems;         // bf16 elements of one precision plane of the image
-    int ablate;              // profiling only (env ISDQN_ABLATE): 1 skip fill, 2 skip K loop, 4 skip epilogue, 8 skip weight fetch
+    int ablate;              // profiling only (env ISDQN_ABLATE): 1 skip fill, 2 skip K loop, 4 skip epilogue
+    long long* stamps;       // profiling only (isdqn_debug_set_stamps): [workgroup][8] s_memtime / s_memrealtime at phase boundaries
 };
 
 template <int MT, int PASSES, bool U8>
@@ -41,18 +42,30 @@ struct ConvImgTraits {
     static constexpr int A_STAGE = A_PLANES * GA::ELEMS;
 };
 
-template <int MT, int PASSES, bool U8>
-__global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvImgParams p) {
+// NW = 4: each wave owns all MT channel tiles of 32 pixels.  NW = 8: two waves per SIMD share the LDS image; wave
+// (mh, pw) owns channel half mh of pixel group pw, and the LayerNorm statistics of a pixel are exchanged through LDS.
+template <int MT, int PASSES, bool U8, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgParams p) {
     using T = ConvImgTraits<MT, PASSES, U8>;
     using GA = typename T::GA;
     constexpr int NT = 2;
+    constexpr int NTHR = NW * 64;
+    constexpr int MTW = NW == 8 ? MT / 2 : MT;  // channel tiles per wave
+    static_assert(NW == 4 || (NW == 8 && MT % 2 == 0), "wave layout");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* a_stage = smem;                              // 2 stages of weight K-slices
     __bf16* img = smem + 2 * T::A_STAGE;                 // B_PLANES planes of the input tile
     const ConvGeom& g = p.g;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, mh = tid >> 8;  // mh = 0 when NW == 4
+#define ISDQN_STAMP(i)                                                                               \
+    if (p.stamps != nullptr && threadIdx.x == 0) {                                                  \
+        p.stamps[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime();           \
+        if ((i) == 0) p.stamps[(int64_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    }
+    ISDQN_STAMP(0);
+    const int mt0 = mh * MTW;
     const int j = (int)blockIdx.x / p.tiles_per_img;
     const int tile = (int)blockIdx.x - j * p.tiles_per_img;
     const int p0 = tile * 128;
@@ -72,25 +85,27 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c < p.fs.stack) fid[c] = p.fs.frame_id(j, c);
-        for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
-            float v[FILL_BATCH][8];
-            int dst[FILL_BATCH];
+        for (int cb = 0; cb < n_chunks; cb += NTHR * FILL_BATCH) {
+            unsigned long long raw[FILL_BATCH];
+            int sh[FILL_BATCH], dst[FILL_BATCH];
 #pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {
-                const int c0 = cb + u * GEMM_THREADS + tid;
+            for (int u = 0; u < FILL_BATCH; ++u) {  // loads only: nothing here touches the loaded registers
+                const int c0 = cb + u * NTHR + tid;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
                 const int cx = cq % cpr, rest = cq / cpr;
                 const int lr = rest % p.R, c = rest / p.R;
                 int id = c == 0 ? fid[0] : c == 1 ? fid[1] : c == 2 ? fid[2] : fid[3];
                 if (c > 3) id = p.fs.frame_id(j, c);
-                p.fs.patch8_id(on ? id : -1, row_base + lr, cx * 8 - g.pad, v[u]);
+                p.fs.patch8_raw(on ? id : -1, row_base + lr, cx * 8 - g.pad, raw[u], sh[u]);
                 dst[u] = on ? ((c * p.R + lr) * p.Wp + cx * 8) : -1;
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
+                float v[8];
+                FrameSrc::patch8_cvt(raw[u], sh[u], v);
                 bf16x8 hi;
-                round8(v[u], hi);
+                round8(v, hi);
                 if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
             }
         }
@@ -98,20 +113,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
         // channel-last: img[lr][xp][cin_p], chunk = 8 channels of one padded pixel
         const int cpp = g.cin_p / 8;
         const int n_chunks = p.R * p.Wp * cpp;
-        for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
+        for (int cb = 0; cb < n_chunks; cb += NTHR * FILL_BATCH) {
             float v[FILL_BATCH][8];
             int dst[FILL_BATCH];
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
-                const int c0 = cb + u * GEMM_THREADS + tid;
+                const int c0 = cb + u * NTHR + tid;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
                 const int cc = cq % cpp, pix = cq / cpp;
                 const int xp = pix % p.Wp, lr = pix / p.Wp;
                 const int iy = row_base + lr, ix = xp - g.pad;
                 const bool ok = on && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-                load8_aligned(p.in + (ok ? (((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + cc * 8 : (int64_t)0), v[u]);
-                mask8(ok, v[u]);
+                load8_aligned(ok ? p.in + ((((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + cc * 8) : zero_chunk(), v[u]);
                 dst[u] = on ? (pix * p.PP + cc * 8) : -1;
             }
 #pragma unroll
@@ -128,6 +142,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
         }
     }
 
+    ISDQN_STAMP(1);  // fill loads consumed, LDS image written (this wave)
     // ---------------- per-lane patch origins of the two 16-pixel column tiles of this wave ----------------
     int b_org[NT];  // element offset of the patch origin inside one image plane
 #pragma unroll
@@ -142,24 +157,27 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
     const int grp = lane >> 4;
 
     // ---------------- weight K-slice staging (A operand, ROW image), as in the generic engine ----------------
-    constexpr int A_PER = GA::PER_THREAD;
+    constexpr int A_PER = (GA::CHUNKS + NTHR - 1) / NTHR;
     int a_row[A_PER], a_var[A_PER], a_lds[A_PER];
     bool a_on[A_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        int c = tid + i * GEMM_THREADS;
+        int c = tid + i * NTHR;
         a_on[i] = c < GA::CHUNKS;
         if (!a_on[i]) c = 0;
         a_row[i] = c >> 2;
         a_var[i] = (c & 3) * 8;
         a_lds[i] = (c >> 2) * GA::PITCH + (c & 3) * 8;
     }
-    float sa[A_PER][8];
-    auto fetch = [&](int k) {
+    // Weight slices are fetched PF steps ahead into a ring of register sets: with one workgroup per CU nothing
+    // else hides the L2 round trip, and one K step of MFMA work is shorter than it.
+    constexpr int PF = 4;
+    float sa[PF][A_PER][8];
+    auto fetch = [&](int slot, int k) {
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) p.W.load(a_row[i], k + a_var[i], sa[i]);
+        for (int i = 0; i < A_PER; ++i) p.W.load(a_row[i], k + a_var[i], sa[slot][i]);
     };
-    auto stash = [&](int stage) {
+    auto stash = [&](int slot, int stage) {
         __bf16* a_hi = a_stage + stage * T::A_STAGE;
         __bf16* a_lo = a_hi + GA::ELEMS;
 #pragma unroll
@@ -167,32 +185,36 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
             if (!a_on[i]) continue;
             bf16x8 hi, lo;
             if constexpr (PASSES >= 2) {
-                split8(sa[i], hi, lo);
+                split8(sa[slot][i], hi, lo);
                 *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
             } else {
-                round8(sa[i], hi);
+                round8(sa[slot][i], hi);
             }
             *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
         }
     };
 
-    f32x4 acc[MT][NT];
+    f32x4 acc[MTW][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = (g.K + GEMM_BK - 1) / GEMM_BK;
     const int k_last = g.K - 8;  // last valid chunk start (weights are zero-filled past K, B only has to stay finite)
 
-    auto compute = [&](int stage, int kk) {
+    // Fragments of one K step: MTW weight tiles and NT pixel tiles, each hi (+ lo).  Two sets alternate so that the
+    // ds_reads of step s+1 are in flight while the MFMAs of step s run (one wave per SIMD: nothing else overlaps them).
+    struct Frags {
+        bf16x8 a_hi[MTW], a_lo[MTW], b_hi[NT], b_lo[NT];
+    };
+    auto read_frags = [&](int stage, int kk, Frags& f) {
         const __bf16* a_hi = a_stage + stage * T::A_STAGE;
         const __bf16* a_lo = a_hi + GA::ELEMS;
-        bf16x8 fa_hi[MT], fa_lo[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            fa_hi[mt] = read_frag<false, GA::PITCH>(a_hi, mt * 16, lane);
-            if constexpr (PASSES >= 2) fa_lo[mt] = read_frag<false, GA::PITCH>(a_lo, mt * 16, lane);
+        for (int mt = 0; mt < MTW; ++mt) {
+            f.a_hi[mt] = read_frag<false, GA::PITCH>(a_hi, (mt0 + mt) * 16, lane);
+            if constexpr (PASSES >= 2) f.a_lo[mt] = read_frag<false, GA::PITCH>(a_lo, (mt0 + mt) * 16, lane);
         }
         // tap / channel of this lane's 8-element chunk
         int kq = kk * GEMM_BK + grp * 8;
@@ -210,114 +232,176 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const __bf16* src = img + b_org[nt] + tap_off;
-            bf16x8 fb_hi, fb_lo;
             if constexpr (U8) {
                 // 8-byte aligned (padded column = 4*ox), two ds_read_b64
                 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
                 bf16x4 h0 = *reinterpret_cast<const bf16x4*>(src);
                 bf16x4 h1 = *reinterpret_cast<const bf16x4*>(src + 4);
-                fb_hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                f.b_hi[nt] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
             } else {
-                fb_hi = *reinterpret_cast<const bf16x8*>(src);
-                if constexpr (PASSES >= 3) fb_lo = *reinterpret_cast<const bf16x8*>(src + p.plane_elems);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if constexpr (PASSES >= 3)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_lo, acc[mt][nt], 0, 0, 0);
-                if constexpr (PASSES >= 2)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[mt], fb_hi, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_hi, acc[mt][nt], 0, 0, 0);
+                f.b_hi[nt] = *reinterpret_cast<const bf16x8*>(src);
+                if constexpr (PASSES >= 3) f.b_lo[nt] = *reinterpret_cast<const bf16x8*>(src + p.plane_elems);
             }
         }
     };
+    auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                if constexpr (PASSES >= 3)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_hi[mt], f.b_lo[nt], acc[mt][nt], 0, 0, 0);
+                if constexpr (PASSES >= 2)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_lo[mt], f.b_hi[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_hi[mt], f.b_hi[nt], acc[mt][nt], 0, 0, 0);
+            }
+    };
 
-    fetch(0);
-    stash(0);
+    // The loop body is straight-line code: a fetch or a stash under a condition ends in a control-flow merge, where
+    // the compiler must choose one wait count that is safe on both paths, which turns the counted vmcnt(N) of the
+    // register ring into vmcnt(0) right behind the fetch.  So the step count is padded to a multiple of PF; slices
+    // past K read the zero block (MatSrc::load) and add nothing.
+    //
+    // Every workgroup streams the SAME weight slices.  Slice s is the 128-byte column block s of every weight row
+    // (rows are K*4 bytes apart), so the workgroups of one XCD, started together, would all pull the same few L2
+    // lines -- one or two L2 channels -- at the same moment.  Each workgroup therefore walks the K steps from its
+    // own starting slice; workgroups b, b+8, b+16, ... share an XCD, hence the rotation by b/8.
+    const int nsteps_p = (nsteps + PF - 1) / PF * PF;
+    const int rot = (p.ablate & 16) ? 0 : (int)((blockIdx.x >> 3) % (unsigned)nsteps);
+    auto slice = [&](int s) {  // K step handled at loop position s; positions past nsteps read zeros
+        const int k = s + rot;
+        return s < nsteps ? (k >= nsteps ? k - nsteps : k) : nsteps_p;
+    };
+    static_assert(PF % 2 == 0, "the fragment sets alternate with the step parity");
+    Frags fr[2];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) fetch(d, slice(d) * GEMM_BK);
+    stash(0, 0);
     __syncthreads();  // image and first weight slice visible
+    ISDQN_STAMP(2);
     if (!(p.ablate & 2)) {
-        for (int s = 0; s < nsteps; ++s) {
-            const bool more = s + 1 < nsteps && !(p.ablate & 8);
-            if (more) fetch((s + 1) * GEMM_BK);
-            compute(s & 1, s);
-            if (more) stash((s + 1) & 1);
-            __syncthreads();
+        // Step s: weights of step s+1 go to LDS stage (s+1)&1 first (its last readers finished before the barrier
+        // that ended step s-1), then -- after the barrier -- the fragments of step s+1 are requested and the MFMAs
+        // of step s run on the set read one step earlier.
+        read_frags(0, slice(0), fr[0]);
+        for (int s0 = 0; s0 < nsteps_p; s0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {  // slot of step s is s % PF = u; it was stashed during step s-1
+                const int s = s0 + u;
+                fetch(u, slice(s + PF) * GEMM_BK);
+                stash((u + 1) % PF, (s + 1) & 1);
+                __syncthreads();                                   // stage (s+1)&1 complete
+                read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);  // in flight during the MFMAs below
+                mfma_step(fr[u & 1]);
+            }
         }
     }
+    ISDQN_STAMP(3);  // K loop done
     if (p.ablate & 4) {
         if (acc[0][0][0] == 12345.678f) p.act[0] = 1.f;  // keep the accumulators alive
         return;
     }
 
     // ---------------- epilogue: bias + LayerNorm over channels + ReLU (same math as ConvFwd::epilogue) -------------
-    float bi[MT][4], ga[MT][4], be[MT][4];
+    float bi[MTW][4], ga[MTW][4], be[MTW][4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int ch = mt * 16 + grp * 4 + r;
+            int ch = (mt0 + mt) * 16 + grp * 4 + r;
             bool ok = ch < g.cout;
             bi[mt][r] = ok ? p.bias[ch] : 0.f;
             ga[mt][r] = (ok && p.gamma) ? p.gamma[ch] : 1.f;
             be[mt][r] = (ok && p.gamma) ? p.beta[ch] : 0.f;
         }
     const float inv_c = 1.0f / (float)g.cout;
+    float zv[NT][MTW][4], s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] = s2[nt] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int ch = (mt0 + mt) * 16 + grp * 4 + r;
+                float zz = ch < g.cout ? acc[mt][nt][r] * p.scale + bi[mt][r] : 0.f;
+                zv[nt][mt][r] = zz;
+                s1[nt] += zz;
+                s2[nt] += zz * zz;
+            }
+        if (p.gamma != nullptr) {
+            s1[nt] += __shfl_xor(s1[nt], 16); s1[nt] += __shfl_xor(s1[nt], 32);
+            s2[nt] += __shfl_xor(s2[nt], 16); s2[nt] += __shfl_xor(s2[nt], 32);
+        }
+    }
+    if constexpr (NW == 8) {
+        if (p.gamma != nullptr) {  // the other channel half of each pixel lives in wave (1 - mh, pw): swap partial sums
+            float* st = reinterpret_cast<float*>(smem);  // weight stages are dead after the K loop's last barrier
+            if (grp == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int px = wave * 32 + nt * 16 + (lane & 15);
+                    st[(mh * 128 + px) * 2] = s1[nt];
+                    st[(mh * 128 + px) * 2 + 1] = s2[nt];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int px = wave * 32 + nt * 16 + (lane & 15);
+                s1[nt] += st[((1 - mh) * 128 + px) * 2];
+                s2[nt] += st[((1 - mh) * 128 + px) * 2 + 1];
+            }
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int pp = p0 + wave * 32 + nt * 16 + (lane & 15);
-        float zv[MT][4];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int ch = mt * 16 + grp * 4 + r;
-                float zz = ch < g.cout ? acc[mt][nt][r] * p.scale + bi[mt][r] : 0.f;
-                zv[mt][r] = zz;
-                s1 += zz;
-                s2 += zz * zz;
-            }
         float mean = 0.f, rstd = 1.f;
         if (p.gamma != nullptr) {
-            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-            mean = s1 * inv_c;
-            float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+            mean = s1[nt] * inv_c;
+            float var = fmaxf(s2[nt] * inv_c - mean * mean, 0.f);
             rstd = rsqrtf(var + 1e-6f);
         }
         if (pp < g.npix) {
             const int64_t pix = (int64_t)j * g.npix + pp;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                int ch0 = mt * 16 + grp * 4;
+            for (int mt = 0; mt < MTW; ++mt) {
+                int ch0 = (mt0 + mt) * 16 + grp * 4;
                 if (ch0 >= g.cout_p) continue;
                 float4 a, zq;
                 float* ap = &a.x;
                 float* zp = &zq.x;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float y = p.gamma != nullptr ? (zv[mt][r] - mean) * (rstd * ga[mt][r]) + be[mt][r] : zv[mt][r];
+                    float y = p.gamma != nullptr ? (zv[nt][mt][r] - mean) * (rstd * ga[mt][r]) + be[mt][r] : zv[nt][mt][r];
                     ap[r] = (ch0 + r < g.cout) ? fmaxf(y, 0.f) : 0.f;
-                    zp[r] = zv[mt][r];
+                    zp[r] = zv[nt][mt][r];
                 }
                 *reinterpret_cast<float4*>(p.act + pix * g.cout_p + ch0) = a;
                 if (j < p.z_img) *reinterpret_cast<float4*>(p.z + pix * g.cout_p + ch0) = zq;
             }
         }
     }
+    ISDQN_STAMP(4);  // epilogue stores issued
+    if (p.stamps != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0);
+        ISDQN_STAMP(5);  // stores retired
+    }
+#undef ISDQN_STAMP
 }
 
-template <int MT, int PASSES, bool U8>
+template <int MT, int PASSES, bool U8, int NW>
 static int launch_conv_fwd_img(const ConvImgParams& p, hipStream_t st) {
     using T = ConvImgTraits<MT, PASSES, U8>;
     const int lds = (2 * T::A_STAGE + T::B_PLANES * p.plane_elems) * 2;
     static int configured_for = 0;
     if (lds > 65536 && lds > configured_for) {
-        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_img_kernel<MT, PASSES, U8>),
+        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_img_kernel<MT, PASSES, U8, NW>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured_for = lds;
     }
-    hipLaunchKernelGGL((conv_fwd_img_kernel<MT, PASSES, U8>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS), lds,
+    hipLaunchKernelGGL((conv_fwd_img_kernel<MT, PASSES, U8, NW>), dim3(p.n_img * p.tiles_per_img), dim3(NW * 64), lds,
                        st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
@@ -378,10 +462,10 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
         for (int c = 0; c < 4; ++c)
             if (c < fs.stack) fid[c] = fs.frame_id(j, c);
         for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
-            float v[FILL_BATCH][8];
-            int dst[FILL_BATCH];
+            unsigned long long raw[FILL_BATCH];
+            int sh[FILL_BATCH], dst[FILL_BATCH];
 #pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {
+            for (int u = 0; u < FILL_BATCH; ++u) {  // loads only: nothing here touches the loaded registers
                 const int c0 = cb + u * GEMM_THREADS + tid;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
@@ -389,13 +473,15 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
                 const int lr = rest % R, c = rest / R;
                 int id = c == 0 ? fid[0] : c == 1 ? fid[1] : c == 2 ? fid[2] : fid[3];
                 if (c > 3) id = fs.frame_id(j, c);
-                fs.patch8_id(on ? id : -1, row_base + lr, cx * 8 - g.pad, v[u]);
+                fs.patch8_raw(on ? id : -1, row_base + lr, cx * 8 - g.pad, raw[u], sh[u]);
                 dst[u] = on ? ((c * R + lr) * Wp + cx * 8) : -1;
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
+                float v[8];
+                FrameSrc::patch8_cvt(raw[u], sh[u], v);
                 bf16x8 hi;
-                round8(v[u], hi);
+                round8(v, hi);
                 if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
             }
         }
@@ -414,8 +500,7 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
                 const int xp = pix % Wp, lr = pix / Wp;
                 const int iy = row_base + lr, ix = xp - g.pad;
                 const bool ok = on && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-                load8_aligned(in + (ok ? (((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + cc * 8 : (int64_t)0), v[u]);
-                mask8(ok, v[u]);
+                load8_aligned(ok ? in + ((((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + cc * 8) : zero_chunk(), v[u]);
                 dst[u] = on ? (pix * g.cin_p + cc * 8) : -1;
             }
 #pragma unroll
@@ -494,8 +579,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const Conv
                     const int cq = on ? c0 : 0;
                     const int cc = cq % cpr, pix = cq / cpr;
                     const bool ok = on && pix < g.npix;
-                    load8_aligned(p.dz + (ok ? ((int64_t)j * g.npix + pix) * g.cout_p + cc * 8 : (int64_t)0), v[u]);
-                    mask8(ok, v[u]);
+                    load8_aligned(ok ? p.dz + (((int64_t)j * g.npix + pix) * g.cout_p + cc * 8) : zero_chunk(), v[u]);
                     dst[u] = on ? (pix * p.PA + cc * 8) : -1;
                 }
 #pragma unroll
@@ -656,8 +740,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
                 const int xp = pix % p.Wd, yp = pix / p.Wd;
                 const int oy = yp - p.bt, ox = xp - p.bt;
                 const bool ok = on && oy >= 0 && oy < g.hout && ox >= 0 && ox < g.wout;
-                load8_aligned(p.dz + (ok ? (((int64_t)j * g.hout + oy) * g.wout + ox) * g.cout_p + cc * 8 : (int64_t)0), v[u]);
-                mask8(ok, v[u]);
+                load8_aligned(ok ? p.dz + ((((int64_t)j * g.hout + oy) * g.wout + ox) * g.cout_p + cc * 8) : zero_chunk(), v[u]);
                 dst[u] = on ? (pix * p.PPd + cc * 8) : -1;
             }
 #pragma unroll
@@ -713,8 +796,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
             g.d_coutp.divmod(ok ? (uint32_t)k : 0u, jt, co);
             const int jy = (int)jt / p.T, jx = (int)jt % p.T;
             const int ky = py + g.stride * jy, kx = px + g.stride * jx;
-            load8_aligned(p.W + (ok ? (int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + a_ci0[i] : (int64_t)0), sa[i]);
-            mask8(ok, sa[i]);
+            load8_aligned(ok ? p.W + ((int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + a_ci0[i]) : zero_chunk(), sa[i]);
         }
     };
     auto stash = [&](int stage) {

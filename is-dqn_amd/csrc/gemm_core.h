@@ -283,18 +283,33 @@ __device__ __forceinline__ void zero8(float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = 0.f;
 }
-// Loaders are BRANCH-FREE: the address is clamped to a valid one, the load is unconditional and the result
-// is selected afterwards.  A load inside a divergent `if` makes hipcc branch around it and wait for it
-// (s_waitcnt at the join), which serialises every chunk of a K step into its own L2 round trip.
-__device__ __forceinline__ void mask8(bool ok, float (&v)[8]) {
+// Loaders are BRANCH-FREE and MASK-FREE.  A load inside a divergent `if` makes hipcc branch around it and wait
+// for it (s_waitcnt at the join); a select on the loaded registers right after the load (v = ok ? v : 0) is no
+// better: it is a use of the data, so the compiler waits (vmcnt(0)) at the load site and a "prefetch" issued
+// before a K step's MFMA work becomes a synchronous round trip.  Out-of-range chunks are therefore read from a
+// block of zeros (`zero_chunk()`): the select happens on the ADDRESS, before the load, and the data registers are
+// not touched until the consumer converts them for LDS.
+static __device__ const float isdqn_zero_block[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                      0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ const float* zero_chunk() { return isdqn_zero_block; }
+__device__ __forceinline__ void mask8(bool ok, float (&v)[8]) {  // for data that is already being consumed
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = ok ? v[i] : 0.f;
 }
+// Every pointer these loaders see is device global memory; saying so keeps the loads `global_load` even when the
+// address was selected between a kernel argument and the zero block (a generic pointer would become `flat_load`,
+// which counts on both wait counters and completes out of order, so every wait turns into vmcnt(0) lgkmcnt(0)).
+#define ISDQN_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ void load8_aligned(const float* p, float (&v)[8]) {
-    float4 a = *reinterpret_cast<const float4*>(p);
-    float4 b = *reinterpret_cast<const float4*>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    const ISDQN_GLOBAL f32x4* gp = (const ISDQN_GLOBAL f32x4*)p;
+    const f32x4 a = gp[0];
+    const f32x4 b = gp[1];
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ unsigned long long load_u64_unaligned(const uint8_t* p) {
+    typedef unsigned long long __attribute__((aligned(1))) u64_u;
+    return *(const ISDQN_GLOBAL u64_u*)p;
 }
 
 // Matrix X[rows][ld] (row-major).  `inner` bounds the contiguous index, `outer` the strided one.
@@ -309,11 +324,10 @@ struct MatSrc {
     template <bool ALIGNED = true>
     __device__ __forceinline__ void load(int o, int i0, float (&v)[8]) const {
         const bool ok = (o < outer) && (i0 < inner);
-        const float* p = base + (ok ? (int64_t)o * ld + i0 : (int64_t)0);
         if constexpr (ALIGNED) {
-            load8_aligned(p, v);
-            mask8(ok, v);
+            load8_aligned(ok ? base + (int64_t)o * ld + i0 : zero_chunk(), v);
         } else {
+            const float* p = base + (ok ? (int64_t)o * ld + i0 : (int64_t)0);
             const int last = ok ? inner - 1 - i0 : 0;  // last valid element offset in this chunk
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

@@ -348,6 +348,357 @@ __global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Head chain (learn path).  Everything between the last hidden activation and the gradient w.r.t. that
+// layer's pre-activation is per-transition work on a few hundred floats, so one kernel does it for S
+// transitions per workgroup instead of five latency-bound launches:
+//   q = a W_head^T + b           (dqn.py:100-103; online rows 0..S-1 and next-state rows S..2S-1 form one
+//                                  16-row MFMA tile, the waves split the contraction and reduce through LDS)
+//   iterated Bellman target, squared TD loss, dL/dq   (isdqn.py:92-109, as td_kernel)
+//   da = dL/dq W_head            (dL/dq has one non-zero per head and transition: K fp32 row-AXPYs, exact)
+//   dz = backward of a = relu(LN(z)) over the hidden row (as ln_bwd_wide_kernel), partial (dgamma, dbeta,
+//        dbias) sums per workgroup to part[wg][3][Fp]
+// Workgroup 0 also advances the Adam step counter (it used to ride on loss_finalize_kernel, which now runs
+// off the critical path).
+// ---------------------------------------------------------------------------------------------
+struct HeadChainParams {
+    const float* act;   // [2B][Fp] hidden activations: online rows, then next-state rows
+    const float* z;     // [B][Fp]  hidden pre-activations of the online rows
+    const float* W;     // [O][Fp]
+    const float* bias;  // [O]
+    const float* gamma; // hidden LayerNorm scale / bias, or null
+    const float* beta;
+    int B, S, F, Fp, O, Op, K, A;
+    const int* action;
+    const float* reward;
+    const uint8_t* terminal;
+    float gamma_n;
+    float* dout;        // [B][Op]  dL/dq
+    float* dz;          // [B][Fp]
+    float* part;        // [n_wg][3][Fp]
+    float* q_values;    // [B][K]
+    float* targets;     // [B][K]
+    double* priorities; // [B] or null
+    float* loss_part;   // [n_wg][K]
+    float* dbh_part;    // [n_wg][Op]
+    int* adam_count;
+    float b1, b2;
+    float* adam_consts;
+};
+
+constexpr int HC_MAX_S = 4;     // transitions per workgroup (online + next rows: half of a 16-row MFMA tile)
+constexpr int HC_MAX_COLS = 4;  // hidden width up to 1024 (columns per thread: template parameter COLS)
+
+__host__ __device__ inline int head_chain_pitch(int Fp) { return (Fp + 31) / 32 * 32 + 8; }
+static inline int head_chain_lds_bytes(int Fp, int Op, int K, int passes) {
+    const int PA = head_chain_pitch(Fp);
+    return (passes >= 2 ? 2 : 1) * 16 * PA * 2 + (4 * 16 * Op + 16 * Op + HC_MAX_S * Op) * 4 + HC_MAX_S * K * 12 +
+           4 * HC_MAX_S * 2 * 4 + 64;
+}
+
+template <int PASSES, int COLS>
+__global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p) {
+    extern __shared__ __attribute__((aligned(16))) char hc_smem[];
+    const int PA = head_chain_pitch(p.Fp);
+    constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
+    __bf16* a_hi = reinterpret_cast<__bf16*>(hc_smem);
+    __bf16* a_lo = a_hi + 16 * PA;
+    float* qpart = reinterpret_cast<float*>(a_hi + A_PLANES * 16 * PA);  // [4][16][Op]
+    float* s_q = qpart + 4 * 16 * p.Op;                                  // [16][Op]
+    float* s_dq = s_q + 16 * p.Op;                                       // [HC_MAX_S][Op]
+    float* s_d = s_dq + HC_MAX_S * p.Op;                                 // [HC_MAX_S][K]
+    float* s_td = s_d + HC_MAX_S * p.K;
+    int* s_wrow = reinterpret_cast<int*>(s_td + HC_MAX_S * p.K);
+    float* s_red = reinterpret_cast<float*>(s_wrow + HC_MAX_S * p.K);    // [4][HC_MAX_S][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = p.S, b0 = (int)blockIdx.x * S;
+    const int Fp = p.Fp, Op = p.Op, K = p.K, A = p.A;
+
+    if (blockIdx.x == 0 && tid == 0) {
+        int t = *p.adam_count + 1;
+        *p.adam_count = t;
+        p.adam_consts[0] = (float)(1.0 - pow((double)p.b1, (double)t));
+        p.adam_consts[1] = (float)(1.0 - pow((double)p.b2, (double)t));
+    }
+
+    // ---- hidden rows -> LDS (bf16 hi/lo, rows >= 2S and columns >= Fp zero) ----
+    {
+        const int cpr = (PA - 8) / 8;
+        for (int c = tid; c < 16 * cpr; c += 256) {
+            const int row = c / cpr, cc = c - row * cpr;
+            const int smp = row < S ? row : row - S;
+            const bool ok = row < 2 * S && b0 + smp < p.B && cc * 8 < Fp;
+            const int64_t grow = row < S ? (int64_t)(b0 + smp) : (int64_t)p.B + b0 + smp;
+            float v[8];
+            load8_aligned(ok ? p.act + (grow * Fp + cc * 8) : zero_chunk(), v);
+            bf16x8 hi, lo;
+            if constexpr (PASSES >= 2) {
+                split8(v, hi, lo);
+                *reinterpret_cast<bf16x8*>(a_lo + row * PA + cc * 8) = lo;
+            } else {
+                round8(v, hi);
+            }
+            *reinterpret_cast<bf16x8*>(a_hi + row * PA + cc * 8) = hi;
+        }
+        for (int i = tid; i < HC_MAX_S * Op; i += 256) s_dq[i] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- q = a W^T : wave w takes K-steps w, w+4, ... of every 16-column tile; the W fragments of two column
+    //      tiles x four K-steps are loaded as one batch so that their L2 latencies overlap ----
+    {
+        const int nkt = (PA - 8) / 32, NT = (Op + 15) / 16;
+        const int kg8 = (lane >> 4) * 8;
+        const int arow = (lane & 15) * PA + kg8;
+        for (int nt = 0; nt < NT; nt += 2) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int ksb = wave; ksb < nkt; ksb += 16) {
+                float v[2][4][8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int o = (nt + t) * 16 + (lane & 15), ks = ksb + 4 * u;
+                        const bool ok = o < p.O && ks < nkt && ks * 32 + kg8 < Fp;
+                        load8_aligned(ok ? p.W + (int64_t)o * Fp + ks * 32 + kg8 : zero_chunk(), v[t][u]);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = min(ksb + 4 * u, nkt - 1);  // past the end: B is zero, A only has to be finite
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_hi + arow + ks * 32);
+                    bf16x8 al;
+                    if constexpr (PASSES >= 2) al = *reinterpret_cast<const bf16x8*>(a_lo + arow + ks * 32);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        bf16x8 bh, bl;
+                        if constexpr (PASSES >= 2) {
+                            split8(v[t][u], bh, bl);
+                            if constexpr (PASSES >= 3)
+                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[t], 0, 0, 0);
+                        } else {
+                            round8(v[t][u], bh);
+                        }
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int o = (nt + t) * 16 + (lane & 15);
+                if (o < Op) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) qpart[(wave * 16 + (lane >> 4) * 4 + r) * Op + o] = acc[t][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * Op; i += 256) {
+        const int o = i % Op;
+        float v = qpart[i] + qpart[16 * Op + i] + qpart[32 * Op + i] + qpart[48 * Op + i];
+        s_q[i] = o < p.O ? v + p.bias[o] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- iterated Bellman target, TD, dL/dq (isdqn.py:92-109) ----
+    const float inv_b = 1.f / (float)p.B;
+    if (tid < S * K) {
+        const int s = tid / K, k = tid - s * K;
+        const int b = b0 + s;
+        float d = 0.f, td = 0.f;
+        int a = 0;
+        if (b < p.B) {
+            a = p.action[b];
+            const float r = p.reward[b], nt = 1.f - (float)p.terminal[b];
+            const float qv = s_q[s * Op + (1 + k) * A + a];
+            const float* nq = s_q + (S + s) * Op + k * A;
+            float mx = nq[0];
+            for (int j = 1; j < A; ++j) mx = fmaxf(mx, nq[j]);
+            const float tg = r + nt * p.gamma_n * mx;
+            d = qv - tg;
+            td = d * d;
+            if (p.q_values) p.q_values[(int64_t)b * K + k] = qv;
+            if (p.targets) p.targets[(int64_t)b * K + k] = tg;
+        }
+        const float dd = 2.f * d * inv_b;
+        s_d[tid] = dd;
+        s_td[tid] = td;
+        s_wrow[tid] = (1 + k) * A + a;
+        s_dq[s * Op + (1 + k) * A + a] = dd;
+    }
+    __syncthreads();
+    for (int i = tid; i < S * Op; i += 256) {
+        const int s = i / Op;
+        if (b0 + s < p.B) p.dout[(int64_t)b0 * Op + i] = s_dq[i];
+    }
+    for (int c = tid; c < Op; c += 256) {
+        float sum = 0.f;
+        for (int s = 0; s < S; ++s) sum += s_dq[s * Op + c];
+        p.dbh_part[(int64_t)blockIdx.x * Op + c] = sum;
+    }
+    if (tid < K) {
+        float sum = 0.f;
+        for (int s = 0; s < S; ++s) sum += s_td[s * K + tid];
+        p.loss_part[(int64_t)blockIdx.x * K + tid] = sum;
+    }
+    if (p.priorities != nullptr && tid < S && b0 + tid < p.B) {
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += s_td[tid * K + k];
+        p.priorities[b0 + tid] = sqrt((double)(sum / (float)K) + 1e-10);
+    }
+
+    // ---- da = dL/dq W (K row-AXPYs per transition), then the LayerNorm/ReLU backward of the hidden row ----
+    float da[HC_MAX_S][COLS], zv[HC_MAX_S][COLS];
+#pragma unroll
+    for (int s = 0; s < HC_MAX_S; ++s)
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) da[s][j] = zv[s][j] = 0.f;
+#pragma unroll
+    for (int s = 0; s < HC_MAX_S; ++s)
+        if (s < S && b0 + s < p.B) {
+#pragma unroll
+            for (int j = 0; j < COLS; ++j) {
+                const int c = tid + j * 256;
+                if (c < p.F) zv[s][j] = p.z[(int64_t)(b0 + s) * Fp + c];
+            }
+        }
+    for (int k0 = 0; k0 < K; k0 += 4) {  // 4 heads x S transitions x COLS columns of W rows in flight
+        float w[HC_MAX_S][4][COLS], dd[HC_MAX_S][4];
+#pragma unroll
+        for (int s = 0; s < HC_MAX_S; ++s)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool on = s < S && k0 + u < K;
+                const int idx = on ? s * K + k0 + u : 0;
+                dd[s][u] = on ? s_d[idx] : 0.f;
+                const float* wr = p.W + (int64_t)s_wrow[idx] * Fp;
+#pragma unroll
+                for (int j = 0; j < COLS; ++j) {
+                    const int c = tid + j * 256;
+                    w[s][u][j] = wr[c < p.F ? c : 0];
+                }
+            }
+#pragma unroll
+        for (int s = 0; s < HC_MAX_S; ++s)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < COLS; ++j) da[s][j] += dd[s][u] * w[s][u][j];
+    }
+    float dg[COLS], db[COLS], dbias[COLS];
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) dg[j] = db[j] = dbias[j] = 0.f;
+    if (p.gamma != nullptr) {
+        float ga[COLS], be[COLS];
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) {
+            const int c = tid + j * 256;
+            ga[j] = c < p.F ? p.gamma[c] : 0.f;
+            be[j] = c < p.F ? p.beta[c] : 0.f;
+        }
+        const float inv_c = 1.f / (float)p.F;
+        float r1[HC_MAX_S], r2[HC_MAX_S];
+        auto block_sum2 = [&]() {  // r1[s], r2[s] summed over the workgroup
+#pragma unroll
+            for (int s = 0; s < HC_MAX_S; ++s)
+                for (int off = 32; off > 0; off >>= 1) {
+                    r1[s] += __shfl_xor(r1[s], off);
+                    r2[s] += __shfl_xor(r2[s], off);
+                }
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int s = 0; s < HC_MAX_S; ++s) {
+                    s_red[(wave * HC_MAX_S + s) * 2] = r1[s];
+                    s_red[(wave * HC_MAX_S + s) * 2 + 1] = r2[s];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < HC_MAX_S; ++s) {
+                r1[s] = s_red[s * 2] + s_red[(HC_MAX_S + s) * 2] + s_red[(2 * HC_MAX_S + s) * 2] + s_red[(3 * HC_MAX_S + s) * 2];
+                r2[s] = s_red[s * 2 + 1] + s_red[(HC_MAX_S + s) * 2 + 1] + s_red[(2 * HC_MAX_S + s) * 2 + 1] +
+                        s_red[(3 * HC_MAX_S + s) * 2 + 1];
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < HC_MAX_S; ++s) {
+            r1[s] = r2[s] = 0.f;
+#pragma unroll
+            for (int j = 0; j < COLS; ++j) {  // zv is zero outside the row / the transition range
+                r1[s] += zv[s][j];
+                r2[s] += zv[s][j] * zv[s][j];
+            }
+        }
+        block_sum2();
+        float mean[HC_MAX_S], rstd[HC_MAX_S];
+#pragma unroll
+        for (int s = 0; s < HC_MAX_S; ++s) {
+            mean[s] = r1[s] * inv_c;
+            rstd[s] = rsqrtf(fmaxf(r2[s] * inv_c - mean[s] * mean[s], 0.f) + 1e-6f);
+            r1[s] = r2[s] = 0.f;
+#pragma unroll
+            for (int j = 0; j < COLS; ++j) {
+                const int c = tid + j * 256;
+                const bool ok = c < p.F && s < S && b0 + s < p.B;
+                const float xh = (zv[s][j] - mean[s]) * rstd[s];
+                const float y = xh * ga[j] + be[j];
+                const float dy = (ok && y > 0.f) ? da[s][j] : 0.f;
+                dg[j] += dy * xh;
+                db[j] += dy;
+                const float g2 = dy * ga[j];
+                da[s][j] = g2;   // keep g
+                zv[s][j] = ok ? xh : 0.f;  // keep xhat
+                r1[s] += g2;
+                r2[s] += g2 * zv[s][j];
+            }
+        }
+        block_sum2();
+#pragma unroll
+        for (int s = 0; s < HC_MAX_S; ++s) {
+            const float m1 = r1[s] * inv_c, m2 = r2[s] * inv_c;
+            if (s < S && b0 + s < p.B) {
+#pragma unroll
+                for (int j = 0; j < COLS; ++j) {
+                    const int c = tid + j * 256;
+                    if (c < Fp) {
+                        const float o = c < p.F ? rstd[s] * (da[s][j] - m1 - zv[s][j] * m2) : 0.f;
+                        dbias[j] += o;
+                        p.dz[(int64_t)(b0 + s) * Fp + c] = o;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < HC_MAX_S; ++s) {
+            if (s < S && b0 + s < p.B) {
+#pragma unroll
+                for (int j = 0; j < COLS; ++j) {
+                    const int c = tid + j * 256;
+                    if (c < Fp) {
+                        const float o = (c < p.F && zv[s][j] > 0.f) ? da[s][j] : 0.f;
+                        dbias[j] += o;
+                        p.dz[(int64_t)(b0 + s) * Fp + c] = o;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+        const int c = tid + j * 256;
+        if (c < Fp) {
+            float* pp = p.part + (int64_t)blockIdx.x * 3 * Fp;
+            pp[c] = dg[j];
+            pp[Fp + c] = db[j];
+            pp[2 * Fp + c] = dbias[j];
+        }
+    }
+}
+
 // losses[k] = mean_b td (isdqn.py:103), optional running sum (update_online_params' cumulated_losses,
 // isdqn.py:62, kept on the device), head-bias gradient, Adam step counter and bias corrections.
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ loss_part,
@@ -356,19 +707,28 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
                                                             float* __restrict__ loss_accum, float* __restrict__ dbh,
                                                             int* adam_count, float b1, float b2,
                                                             float* __restrict__ adam_consts) {
-    const int tid = threadIdx.x;
-    for (int k = tid; k < K; k += 256) {
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    // 16 lanes share one output: strided partial sums, then a fixed shuffle tree
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int k = k0 + grp;
         float s = 0.f;
-        for (int i = 0; i < n_blk; ++i) s += loss_part[(int64_t)i * K + k];
-        s /= (float)B;
-        losses[k] = s;
-        if (loss_accum != nullptr) loss_accum[k] += s;
+        if (k < K)
+            for (int i = sub; i < n_blk; i += 16) s += loss_part[(int64_t)i * K + k];
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (k < K && sub == 0) {
+            s /= (float)B;
+            losses[k] = s;
+            if (loss_accum != nullptr) loss_accum[k] += s;
+        }
     }
     if (dbh != nullptr)
-        for (int c = tid; c < nha_p; c += 256) {
+        for (int c0 = 0; c0 < nha_p; c0 += 16) {
+            const int c = c0 + grp;
             float s = 0.f;
-            for (int i = 0; i < n_blk; ++i) s += dbh_part[(int64_t)i * nha_p + c];
-            dbh[c] = s;
+            if (c < nha_p)
+                for (int i = sub; i < n_blk; i += 16) s += dbh_part[(int64_t)i * nha_p + c];
+            for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            if (c < nha_p && sub == 0) dbh[c] = s;
         }
     if (adam_count != nullptr && tid == 0) {
         int t = *adam_count + 1;
@@ -471,6 +831,17 @@ __global__ void argmax_kernel(const float* __restrict__ q, int A, int head, int*
 // =============================================================================================
 // Host orchestration
 // =============================================================================================
+// profiling hook (not in the public header): phase stamps of the image-resident forward kernel of one layer
+static long long* g_stamps = nullptr;
+static int g_stamp_layer = -1;
+static char g_stamp_name[16] = "";
+extern "C" int isdqn_debug_set_stamps(void* buf, const char* layer_name) {
+    g_stamps = (long long*)buf;
+    g_stamp_layer = buf ? 0 : -1;
+    snprintf(g_stamp_name, sizeof(g_stamp_name), "%s", layer_name ? layer_name : "");
+    return ISDQN_OK;
+}
+
 static ConvGeom conv_geom(const Layer& l) {
     ConvGeom g;
     g.hin = l.hin; g.win = l.win; g.cin_p = l.cin_p; g.hout = l.hout; g.wout = l.wout;
@@ -527,17 +898,28 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     ip.scale = l.is_u8 ? (1.0f / 255.0f) : 1.0f;
     ip.act = act; ip.z = z; ip.n_img = n_img; ip.z_img = z_img;
     ip.tiles_per_img = ceil_div(l.npix, 128);
+    ip.stamps = (g_stamp_layer >= 0 && strcmp(l.name, g_stamp_name) == 0) ? g_stamps : nullptr;
     {
         const char* e = getenv("ISDQN_ABLATE");
         ip.ablate = e ? atoi(e) : 0;
     }
     *done = true;
     if (l.is_u8) {
-        if (passes == 2) return mt == 2 ? launch_conv_fwd_img<2, 2, true>(ip, st) : launch_conv_fwd_img<4, 2, true>(ip, st);
-        return mt == 2 ? launch_conv_fwd_img<2, 1, true>(ip, st) : launch_conv_fwd_img<4, 1, true>(ip, st);
+        static const int nw_u8 = getenv("ISDQN_FWD_NW_U8") ? atoi(getenv("ISDQN_FWD_NW_U8")) : 4;
+        if (nw_u8 == 8) {
+            if (passes == 2) return mt == 2 ? launch_conv_fwd_img<2, 2, true, 8>(ip, st) : launch_conv_fwd_img<4, 2, true, 8>(ip, st);
+            return mt == 2 ? launch_conv_fwd_img<2, 1, true, 8>(ip, st) : launch_conv_fwd_img<4, 1, true, 8>(ip, st);
+        }
+        if (passes == 2) return mt == 2 ? launch_conv_fwd_img<2, 2, true, 4>(ip, st) : launch_conv_fwd_img<4, 2, true, 4>(ip, st);
+        return mt == 2 ? launch_conv_fwd_img<2, 1, true, 4>(ip, st) : launch_conv_fwd_img<4, 1, true, 4>(ip, st);
     }
-    if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false>(ip, st) : launch_conv_fwd_img<4, 3, false>(ip, st);
-    return mt == 2 ? launch_conv_fwd_img<2, 1, false>(ip, st) : launch_conv_fwd_img<4, 1, false>(ip, st);
+    static const int nw = getenv("ISDQN_FWD_NW") ? atoi(getenv("ISDQN_FWD_NW")) : 4;
+    if (nw == 8) {
+        if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false, 8>(ip, st) : launch_conv_fwd_img<4, 3, false, 8>(ip, st);
+        return mt == 2 ? launch_conv_fwd_img<2, 1, false, 8>(ip, st) : launch_conv_fwd_img<4, 1, false, 8>(ip, st);
+    }
+    if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false, 4>(ip, st) : launch_conv_fwd_img<4, 3, false, 4>(ip, st);
+    return mt == 2 ? launch_conv_fwd_img<2, 1, false, 4>(ip, st) : launch_conv_fwd_img<4, 1, false, 4>(ip, st);
 }
 
 static int conv_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int n_img,
@@ -639,9 +1021,10 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInpu
 
 // forward over n_img images; hidden activations -> ws act regions, head output -> q_out [n_img][nha_p]
 static int net_forward(const Plan& P, bool x3, const float* params, const NetInput& in, int n_img, int z_img,
-                       float* ws, float* q_out, hipStream_t st) {
+                       float* ws, float* q_out, hipStream_t st, int n_run = -1) {
     const float* prev = nullptr;
-    for (int i = 0; i < P.n_layers; ++i) {
+    if (n_run < 0) n_run = P.n_layers;
+    for (int i = 0; i < n_run; ++i) {
         const Layer& l = P.L[i];
         float* act = l.is_head ? q_out : ws + l.act_off;
         float* z = l.is_head ? nullptr : ws + l.z_off;
@@ -986,25 +1369,84 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     hipStream_t st = (hipStream_t)stream;
     NetInput in{batch->frames, batch->frame_stride, batch->frame_ids, B, batch->state, batch->next_state, B};
 
+    // ---- head chain eligibility (learn path): last hidden layer dense + ReLU, widths within the kernel's limits ----
+    const Layer& hid = P.L[P.n_layers >= 2 ? P.n_layers - 2 : 0];
+    const Layer& head = P.L[P.n_layers - 1];
+    int hc_S = 0, hc_wg = 0;
+    static const bool hc_disabled = getenv("ISDQN_NO_HEAD_CHAIN") != nullptr;
+    if (learn && !hc_disabled && P.n_layers >= 2 && hid.kind == 1 && !hid.is_head && hid.has_relu &&
+        hid.out_p <= 256 * HC_MAX_COLS && hid.out_p % 8 == 0) {
+        const int n_wg = ceil_div(B, HC_MAX_S);
+        if (n_wg <= hid.part_rows && HC_MAX_S * K <= 256 &&
+            head_chain_lds_bytes(hid.out_p, P.nha_p, K, x3 ? 3 : 1) <= 150 * 1024) {
+            hc_S = HC_MAX_S;
+            hc_wg = n_wg;
+        }
+    }
+    SideStream* ss = learn ? side_stream() : nullptr;
+    hipStream_t wst = ss ? ss->stream : st;  // stream of the weight gradients
+
     // ---- forward on concat(state, next_state) (isdqn.py:95) ----
-    rc = net_forward(P, x3, params, in, P.N2, B, ws, ws + P.q_off, st);
+    rc = net_forward(P, x3, params, in, P.N2, B, ws, ws + P.q_off, st, hc_S ? P.n_layers - 1 : -1);
     if (rc) return rc;
 
     // ---- targets, loss, dL/dq ----
     float* qv = q_values ? q_values : ws + P.qv_off;
     float* tg = targets ? targets : ws + P.tg_off;
-    const int n_blk = ceil_div(B, TD_ROWS);
+    const int n_blk = hc_S ? hc_wg : ceil_div(B, TD_ROWS);
     float* loss_part = ws + P.lpart_off;
     float* dbh_part = loss_part + (int64_t)n_blk * K;
     float* adam_consts = ws + P.adam_tab_off;
-    hipLaunchKernelGGL(td_kernel, dim3(n_blk), dim3(256), 2 * TD_ROWS * K * sizeof(float), st, ws + P.q_off, B, K,
-                       P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n,
-                       learn ? ws + P.dout_off : nullptr, qv, tg, priorities, loss_part, dbh_part);
-    ISDQN_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p, losses,
-                       loss_accum, learn ? ws + P.dbh_off : nullptr, learn ? adam_count : nullptr, cfg->adam_b1,
-                       cfg->adam_b2, adam_consts);
-    ISDQN_HIP_CHECK(hipGetLastError());
+    if (hc_S) {
+        HeadChainParams hp;
+        hp.act = ws + hid.act_off; hp.z = ws + hid.z_off;
+        hp.W = params + head.w_off; hp.bias = params + head.b_off;
+        hp.gamma = hid.has_ln ? params + hid.g_off : nullptr;
+        hp.beta = hid.has_ln ? params + hid.be_off : nullptr;
+        hp.B = B; hp.S = hc_S; hp.F = hid.out_f; hp.Fp = hid.out_p; hp.O = P.nha; hp.Op = P.nha_p; hp.K = K;
+        hp.A = P.n_actions;
+        hp.action = batch->action; hp.reward = batch->reward; hp.terminal = batch->terminal;
+        hp.gamma_n = cfg->gamma_n;
+        hp.dout = ws + P.dout_off; hp.dz = ws + hid.dz_off; hp.part = ws + hid.part_off;
+        hp.q_values = qv; hp.targets = tg; hp.priorities = priorities;
+        hp.loss_part = loss_part; hp.dbh_part = dbh_part;
+        hp.adam_count = adam_count; hp.b1 = cfg->adam_b1; hp.b2 = cfg->adam_b2; hp.adam_consts = adam_consts;
+        const int lds = head_chain_lds_bytes(hid.out_p, P.nha_p, K, x3 ? 3 : 1);
+        const int cols = ceil_div(hid.out_p, 256) <= 1 ? 1 : ceil_div(hid.out_p, 256) <= 2 ? 2 : 4;
+        auto launch_hc = [&](auto kern, int slot) -> int {
+            static int configured[6] = {0, 0, 0, 0, 0, 0};
+            if (lds > 65536 && lds > configured[slot]) {
+                ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                configured[slot] = lds;
+            }
+            hipLaunchKernelGGL(kern, dim3(hc_wg), dim3(256), lds, st, hp);
+            ISDQN_HIP_CHECK(hipGetLastError());
+            return ISDQN_OK;
+        };
+        if (x3) rc = cols == 1 ? launch_hc(&head_chain_kernel<3, 1>, 0) : cols == 2 ? launch_hc(&head_chain_kernel<3, 2>, 1)
+                                                                                     : launch_hc(&head_chain_kernel<3, 4>, 2);
+        else rc = cols == 1 ? launch_hc(&head_chain_kernel<1, 1>, 3) : cols == 2 ? launch_hc(&head_chain_kernel<1, 2>, 4)
+                                                                                  : launch_hc(&head_chain_kernel<1, 4>, 5);
+        if (rc) return rc;
+        // loss / head-bias reductions and the head's weight gradient leave the critical path
+        if (ss) {
+            rc = chain(ss, st, wst);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, wst, loss_part, dbh_part, n_blk, B, K, P.nha_p,
+                           losses, loss_accum, ws + P.dbh_off, (int*)nullptr, cfg->adam_b1, cfg->adam_b2, adam_consts);
+        ISDQN_HIP_CHECK(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(td_kernel, dim3(n_blk), dim3(256), 2 * TD_ROWS * K * sizeof(float), st, ws + P.q_off, B, K,
+                           P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n,
+                           learn ? ws + P.dout_off : nullptr, qv, tg, priorities, loss_part, dbh_part);
+        ISDQN_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p,
+                           losses, loss_accum, learn ? ws + P.dbh_off : nullptr, learn ? adam_count : nullptr,
+                           cfg->adam_b1, cfg->adam_b2, adam_consts);
+        ISDQN_HIP_CHECK(hipGetLastError());
+    }
     if (!learn) return ISDQN_OK;
 
     // ---- backward (online rows only: the next-state half has a zero cotangent, isdqn.py:99) ----
@@ -1020,15 +1462,19 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     const float* dz_cur = ws + P.dout_off;  // gradient w.r.t. the current layer's pre-activation output
     int dz_ld = P.nha_p;
     bool dz_fused = false;  // dz of layer i was already produced by the fused data gradient of layer i+1
-    SideStream* ss = side_stream();
-    hipStream_t wst = ss ? ss->stream : st;  // stream of the weight gradients
     for (int i = P.n_layers - 1; i >= 0; --i) {
         const Layer& l = P.L[i];
         const float* act_in = i > 0 ? ws + P.L[i - 1].act_off : nullptr;
         if (!l.is_head) {
             dz_cur = ws + l.dz_off;
             dz_ld = l.out_p;
-            if (dz_fused) {
+            if (hc_S && i == P.n_layers - 2) {  // dz and the partial sums came from the head chain
+                if (l.has_ln) {
+                    add_entry(l.g_off, l.out_p, ws + l.part_off, hc_wg, 3 * (int64_t)l.out_p);
+                    add_entry(l.be_off, l.out_p, ws + l.part_off + l.out_p, hc_wg, 3 * (int64_t)l.out_p);
+                }
+                add_entry(l.b_off, l.out_p, ws + l.part_off + 2 * l.out_p, hc_wg, 3 * (int64_t)l.out_p);
+            } else if (dz_fused) {
                 if (l.has_ln) {
                     add_entry(l.g_off, l.out_p, ws + l.red_off, 1, 0);
                     add_entry(l.be_off, l.out_p, ws + l.red_off + l.out_p, 1, 0);
@@ -1052,11 +1498,12 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         // Weight gradients of the middle layers go to the side stream.  Every fork costs the main stream an event
         // record (a ~6 us bubble), so the head's tiny weight gradient and the first layer's (nothing is left to
         // overlap with) stay on the main stream, and a layer whose Adam is fused forks once, after its data gradient.
+        const bool head_chained = l.is_head && hc_S;  // the fork happened right after the head chain
         const bool wg_on_side = ss && !l.is_head && i > 0;
-        hipStream_t lws = wg_on_side ? wst : st;
+        hipStream_t lws = (wg_on_side || head_chained) ? wst : st;
         const bool fork_after_dgrad = wg_on_side && l.kind == 1;
         if (wg_on_side && !fork_after_dgrad) {  // dz of this layer is final on the main stream
-            rc = chain(ss, st, wst);
+            rc = chain(ss, st, lws);
             if (rc) return rc;
         }
         // data gradient for the layer below first: it reads this layer's weights, which the fused-Adam
@@ -1091,7 +1538,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 ISDQN_HIP_CHECK(hipGetLastError());
                 dz_fused = true;
             }
-            if (dz_fused) {
+            if (dz_fused || head_chained) {
             } else if (l.kind == 0) {
                 const bool small = l.cin_p <= 32;
                 if (x3) rc = small ? launch_conv_dgrad<32, 3>(l, params, dz_cur, ws + P.da_off, B, st)
@@ -1111,7 +1558,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         }
         // weight gradient -> slabs (or straight into Adam when one workgroup holds the whole contraction)
         if (fork_after_dgrad) {  // dz is final AND the data gradient (which reads W) is enqueued: an in-place
-            rc = chain(ss, st, wst);  // fused-Adam update on the side stream cannot overtake it
+            rc = chain(ss, st, lws);  // fused-Adam update on the side stream cannot overtake it
             if (rc) return rc;
         }
         int w_slabs;

@@ -196,6 +196,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
             l.z_off = region(std::string("z/") + l.name, (int64_t)P.B * l.out_elems_p);
             l.dz_off = region(std::string("dz/") + l.name, (int64_t)P.B * l.out_elems_p);
             l.part_rows = LN_MAX_BLOCKS;
+            if (l.kind == 1 && ceil_div(P.B, 4) > l.part_rows) l.part_rows = ceil_div(P.B, 4);  // head chain: one row per 4 transitions
             l.part_off = -2;  // sized below, once the consumer layer's tiling is known
             l.red_off = region(std::string("red/") + l.name, 3 * (int64_t)l.out_p);
         }
@@ -261,7 +262,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
     P.tg_off = region("targets", (int64_t)P.B * (P.n_heads - 1));
     P.dbh_off = region("dbh", P.nha_p);
     P.adam_tab_off = region("adam_consts", 64);
-    P.lpart_off = region("loss_partials", (int64_t)ceil_div(P.B, 64) * (P.n_heads - 1 + P.nha_p));
+    P.lpart_off = region("loss_partials", (int64_t)ceil_div(P.B, 4) * (P.n_heads - 1 + P.nha_p));
     P.ws_bytes = off * 4;
     return ISDQN_OK;
 }

@@ -33,20 +33,30 @@ struct FrameSrc {
     // 8 horizontally adjacent pixels (ix0 .. ix0+7) of row iy of frame `id`, zero outside the frame; exact in
     // bf16.  Branch-free: one unaligned 8-byte load from a clamped position, then a 64-bit shift moves the
     // bytes into place and shifts zeros in for the columns that fall outside the row (needs W >= 8).
-    __device__ __forceinline__ void patch8_id(int id, int iy, int ix0, float (&v)[8]) const {
+    // Two-phase form: `patch8_raw` only issues the (unaligned) 8-byte load -- out-of-image patches read a block of
+    // zeros, so nothing touches the loaded registers -- and `patch8_cvt` shifts the border in and converts.  Callers
+    // that prefetch keep `raw` and `d` and convert when they stage to LDS.
+    __device__ __forceinline__ void patch8_raw(int id, int iy, int ix0, unsigned long long& raw, int& d) const {
         const bool ok = (id >= 0) && (iy >= 0) && (iy < H) && (ix0 > -8) && (ix0 < W);
         const int ixc = min(max(ix0, 0), W - 8);
-        const uint8_t* row = frames + (ok ? (int64_t)id * stride + (int64_t)iy * W + ixc : (int64_t)0);
-        unsigned long long u;
-        __builtin_memcpy(&u, row, 8);  // one (unaligned) global_load_dwordx2
-        const int d = ix0 - ixc;       // < 0: left border, > 0: right border
+        const uint8_t* row = ok ? frames + ((int64_t)id * stride + (int64_t)iy * W + ixc)
+                                : reinterpret_cast<const uint8_t*>(zero_chunk());
+        raw = load_u64_unaligned(row);   // one (unaligned) global_load_dwordx2
+        d = ix0 - ixc;                   // < 0: left border, > 0: right border
+    }
+    static __device__ __forceinline__ void patch8_cvt(unsigned long long u, int d, float (&v)[8]) {
         u = d >= 0 ? (u >> (8 * d)) : (u << (8 * (-d)));
-        u = ok ? u : 0ull;
         const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
         v[0] = (float)(lo & 0xff); v[1] = (float)((lo >> 8) & 0xff);
         v[2] = (float)((lo >> 16) & 0xff); v[3] = (float)(lo >> 24);
         v[4] = (float)(hi & 0xff); v[5] = (float)((hi >> 8) & 0xff);
         v[6] = (float)((hi >> 16) & 0xff); v[7] = (float)(hi >> 24);
+    }
+    __device__ __forceinline__ void patch8_id(int id, int iy, int ix0, float (&v)[8]) const {
+        unsigned long long u;
+        int d;
+        patch8_raw(id, iy, ix0, u, d);
+        patch8_cvt(u, d, v);
     }
     __device__ __forceinline__ void patch8(int j, int c, int iy, int ix0, float (&v)[8]) const {
         patch8_id(frame_id(j, c), iy, ix0, v);
@@ -372,9 +382,7 @@ struct ConvFwd {
             g.d_ksz.divmod(tap, ky, kx);
             const int iy = c.iy0 + (int)ky, ix = c.ix0 + (int)kx;
             const bool ok = kok && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-            const float* p = in + (ok ? (((int64_t)c.j * g.hin + iy) * g.win + ix) * g.cin_p + ci : (int64_t)0);
-            load8_aligned(p, v);
-            mask8(ok, v);
+            load8_aligned(ok ? in + ((((int64_t)c.j * g.hin + iy) * g.win + ix) * g.cin_p + ci) : zero_chunk(), v);
         }
     }
     template <int MT, int NT>
@@ -480,8 +488,7 @@ struct ConvDgrad {
         g.d_coutp.divmod(ok ? k : 0, jt, co);
         int jy = (int)jt / T, jx = (int)jt % T;
         int ky = t.py + g.stride * jy, kx = t.px + g.stride * jx;
-        load8_aligned(W + (ok ? (int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + c.ci0 : (int64_t)0), v);
-        mask8(ok, v);
+        load8_aligned(ok ? W + ((int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + c.ci0) : zero_chunk(), v);
     }
     __device__ __forceinline__ void decode(const Tile& t, int q, int& j, int& iy, int& ix) const {
         uint32_t jj, rem, a, b;
@@ -505,8 +512,7 @@ struct ConvDgrad {
         int jy = (int)jt / T, jx = (int)jt % T;
         int oy = c.oyb - jy, ox = c.oxb - jx;
         const bool ok = kok && oy >= 0 && oy < g.hout && ox >= 0 && ox < g.wout;
-        load8_aligned(dz + (ok ? (((int64_t)c.j * g.hout + oy) * g.wout + ox) * g.cout_p + co : (int64_t)0), v);
-        mask8(ok, v);
+        load8_aligned(ok ? dz + ((((int64_t)c.j * g.hout + oy) * g.wout + ox) * g.cout_p + co) : zero_chunk(), v);
     }
     template <int MT, int NT>
     __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane, char* smem) const {
@@ -581,8 +587,7 @@ struct ConvWgrad {
             fs.patch8_id(pok ? id : -1, iy, ix, v);
         } else {
             const bool ok = pok && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-            load8_aligned(in + (ok ? (((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + c.c_or_ci : (int64_t)0), v);
-            mask8(ok, v);
+            load8_aligned(ok ? in + ((((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + c.c_or_ci) : zero_chunk(), v);
         }
     }
     template <int MT, int NT>

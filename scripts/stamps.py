@@ -1,0 +1,57 @@
+"""In-kernel phase stamps of the image-resident forward conv kernel of one layer (debug hook), inside a full
+learn step.  Prints per-phase medians in microseconds (s_memtime ticks are shader cycles; the clock is derived
+from kernel-wide span vs s_memrealtime at 100 MHz)."""
+import os, sys, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "is-dqn_amd"))
+import numpy as np, torch
+from slimdqn._engine import QNetEngine
+from slimdqn import _hip
+
+layer = sys.argv[1] if len(sys.argv) > 1 else "Conv_1"
+B, K, A = int(os.environ.get("B", "256")), 9, 9
+eng = QNetEngine((84, 84, 4), A, 1 + K, (32, 64, 64, 512), "cnn", True, B, gamma_n=0.99, learning_rate=6.25e-5, adam_eps=1.5e-4)
+eng.init_params(0)
+nf = 1_000_000
+g = torch.Generator(device="cuda").manual_seed(0)
+frames = torch.randint(0, 256, (nf, 84 * 84), dtype=torch.uint8, device="cuda", generator=g)
+base = torch.randint(0, nf - 8, (B, 1), device="cuda", generator=g)
+ids = (base + torch.arange(4, device="cuda")[None, :]).int()
+ids = torch.cat([ids, ids + 1], 1).contiguous()
+batch = eng.make_batch(frames=frames, frame_stride=84 * 84, frame_ids=ids, action=torch.randint(0, A, (B,), device="cuda", generator=g).int(),
+                       reward=torch.randn(B, device="cuda", generator=g), terminal=torch.zeros(B, dtype=torch.uint8, device="cuda"))
+for _ in range(5):
+    eng.learn_on_batch(batch)
+nwg = 4096
+st = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
+lib = _hip.lib()
+lib.isdqn_debug_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+lib.isdqn_debug_set_stamps(ctypes.c_void_p(st.data_ptr()), layer.encode())
+eng.learn_on_batch(batch)
+torch.cuda.synchronize()
+lib.isdqn_debug_set_stamps(None, b"")
+s = st.cpu().numpy().reshape(nwg, 8)
+s = s[s[:, 7] != 0]  # column 7 (s_memrealtime) is written by the workgroup-level stamp 0 only
+print(layer, "workgroups", len(s))
+t0 = s[:, 0].min()
+span_cyc = s[:, 5].max() - t0
+span_rt = (s[:, 7].max() - s[:, 7].min())  # start-to-last-start only; use as lower bound
+order = np.argsort(s[:, 0])
+names = ["fill(load+convert+write)", "weights0+sync", "K loop", "epilogue issue", "store drain"]
+d = np.diff(s[:, :6], axis=1)
+ghz = float(os.environ.get("GHZ", "2.0"))
+print("start spread (cyc): p50 %.0f  p99 %.0f  max %.0f" % tuple(np.percentile(s[:, 0] - t0, [50, 99, 100])))
+for i, n in enumerate(names):
+    print(f"{n:28s} median {np.median(d[:, i]):9.0f} cyc  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}   ~{np.median(d[:, i]) / ghz / 1e3:6.2f} us @ {ghz} GHz")
+print("per-WG total median", np.median(s[:, 5] - s[:, 0]), "cyc; kernel span", span_cyc, "cyc")
+# first-round vs second-round workgroups
+late = (s[:, 0] - t0) > 0.3 * span_cyc
+print("workgroups starting late (2nd round):", late.sum())
+# optional step-level stamps (diagnostic build only): second row block
+s2 = st.cpu().numpy().reshape(nwg, 8)
+g = len(s)
+rows = s2[g:2 * g]
+if rows[:, 0].any():
+    dd = np.diff(rows[:, :5], axis=1)
+    for i, n in enumerate(["A frag reads", "tap calc + B reads + MFMA issue", "stash (vmcnt wait + cvt + ds_write)", "barrier"]):
+        print(f"  step: {n:40s} median {np.median(dd[:, i]):7.0f} cyc  p90 {np.percentile(dd[:, i], 90):7.0f}")
