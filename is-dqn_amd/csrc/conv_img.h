@@ -786,8 +786,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
         a_ci0[i] = rc * 8; a_kk[i] = kk;
         a_lds[i] = kk * GA::PITCH + rc * 8;
     }
-    float sa[A_PER][8];
-    auto fetch = [&](int k0) {
+    constexpr int PF = 4;  // weight slices in flight (register ring), as in conv_fwd_img_kernel
+    float sa[PF][A_PER][8];
+    auto fetch = [&](int slot, int k0) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int k = k0 + a_kk[i];
@@ -796,10 +797,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
             g.d_coutp.divmod(ok ? (uint32_t)k : 0u, jt, co);
             const int jy = (int)jt / p.T, jx = (int)jt % p.T;
             const int ky = py + g.stride * jy, kx = px + g.stride * jx;
-            load8_aligned(ok ? p.W + ((int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + a_ci0[i]) : zero_chunk(), sa[i]);
+            load8_aligned(ok ? p.W + ((int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + a_ci0[i]) : zero_chunk(), sa[slot][i]);
         }
     };
-    auto stash = [&](int stage) {
+    auto stash = [&](int slot, int stage) {
         __bf16* a_hi = a_stage + stage * A_STAGE;
         __bf16* a_lo = a_hi + GA::ELEMS;
 #pragma unroll
@@ -807,10 +808,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
             if (!a_on[i]) continue;
             bf16x8 hi, lo;
             if constexpr (PASSES >= 2) {
-                split8(sa[i], hi, lo);
+                split8(sa[slot][i], hi, lo);
                 *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
             } else {
-                round8(sa[i], hi);
+                round8(sa[slot][i], hi);
             }
             *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
         }
@@ -824,14 +825,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
 
     const int nsteps = (p.Kc + GEMM_BK - 1) / GEMM_BK;
     const int k_last = p.Kc - 8;
-    auto compute = [&](int stage, int kk) {
+    struct Frags {
+        bf16x8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
+    };
+    auto read_frags = [&](int stage, int kk, Frags& f) {
         const __bf16* a_hi = a_stage + stage * A_STAGE;
         const __bf16* a_lo = a_hi + GA::ELEMS;
-        bf16x8 fa_hi[MT], fa_lo[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            fa_hi[mt] = read_frag<true, GA::PITCH>(a_hi, mt * 16, lane);
-            if constexpr (PASSES >= 2) fa_lo[mt] = read_frag<true, GA::PITCH>(a_lo, mt * 16, lane);
+            f.a_hi[mt] = read_frag<true, GA::PITCH>(a_hi, mt * 16, lane);
+            if constexpr (PASSES >= 2) f.a_lo[mt] = read_frag<true, GA::PITCH>(a_lo, mt * 16, lane);
         }
         int kq = kk * GEMM_BK + grp * 8;
         kq = kq < k_last ? kq : k_last;
@@ -842,28 +845,62 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const __bf16* src = img + b_org[nt] + tap_off;
-            bf16x8 fb_hi = *reinterpret_cast<const bf16x8*>(src), fb_lo;
-            if constexpr (PASSES >= 3) fb_lo = *reinterpret_cast<const bf16x8*>(src + p.dz_plane);
+            f.b_hi[nt] = *reinterpret_cast<const bf16x8*>(src);
+            if constexpr (PASSES >= 3) f.b_lo[nt] = *reinterpret_cast<const bf16x8*>(src + p.dz_plane);
+        }
+    };
+    auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (PASSES >= 3)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_lo, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_hi[mt], f.b_lo[nt], acc[mt][nt], 0, 0, 0);
                 if constexpr (PASSES >= 2)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[mt], fb_hi, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_hi, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_lo[mt], f.b_hi[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_hi[mt], f.b_hi[nt], acc[mt][nt], 0, 0, 0);
             }
-        }
     };
 
-    fetch(0);
-    stash(0);
+    // pre-activations of the layer below for the epilogue: requested now, they arrive under the K loop
+    float zpre[NT][MT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t pixel = ((int64_t)j * g.hin + pix_iy[nt]) * g.win + pix_ix[nt];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int ch0 = mt * 16 + grp * 4;
+            const ISDQN_GLOBAL f32x4* zp = (const ISDQN_GLOBAL f32x4*)(ch0 < g.cin_p ? p.z_in + pixel * g.cin_p + ch0 : zero_chunk());
+            const f32x4 zq = *zp;
+            zpre[nt][mt][0] = zq[0]; zpre[nt][mt][1] = zq[1]; zpre[nt][mt][2] = zq[2]; zpre[nt][mt][3] = zq[3];
+        }
+    }
+
+    // straight-line main loop (see conv_fwd_img_kernel): register ring of PF slices, fragments of step s+1 read
+    // while the MFMAs of step s run; workgroups of one XCD start at different slices
+    static_assert(PF % 2 == 0, "the fragment sets alternate with the step parity");
+    const int nsteps_p = (nsteps + PF - 1) / PF * PF;
+    const int rot = (int)((blockIdx.x >> 3) % (unsigned)nsteps);
+    auto slice = [&](int s) {
+        const int k = s + rot;
+        return s < nsteps ? (k >= nsteps ? k - nsteps : k) : nsteps_p;
+    };
+    Frags fr[2];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) fetch(d, slice(d) * GEMM_BK);
+    stash(0, 0);
     __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const bool more = s + 1 < nsteps;
-        if (more) fetch((s + 1) * GEMM_BK);
-        compute(s & 1, s);
-        if (more) stash((s + 1) & 1);
-        __syncthreads();
+    read_frags(0, slice(0), fr[0]);
+    for (int s0 = 0; s0 < nsteps_p; s0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int s = s0 + u;
+            fetch(u, slice(s + PF) * GEMM_BK);
+            stash((u + 1) % PF, (s + 1) & 1);
+            __syncthreads();
+            read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
+            mfma_step(fr[u & 1]);
+        }
     }
 
     // ---- epilogue: LayerNorm + ReLU backward of the layer below, per input pixel (column) ----
@@ -885,12 +922,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
         const int64_t pixel = ((int64_t)j * g.hin + pix_iy[nt]) * g.win + pix_ix[nt];
         float zv[MT][4];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int ch0 = mt * 16 + grp * 4;
-            float4 zq = float4{0.f, 0.f, 0.f, 0.f};
-            if (ch0 < g.cin_p) zq = *reinterpret_cast<const float4*>(p.z_in + pixel * g.cin_p + ch0);
-            zv[mt][0] = zq.x; zv[mt][1] = zq.y; zv[mt][2] = zq.z; zv[mt][3] = zq.w;
-        }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zv[mt][r] = zpre[nt][mt][r];
         float out[MT][4];
         if (p.gamma != nullptr) {
             float s1 = 0.f, s2 = 0.f;

@@ -1145,7 +1145,9 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
         if (mt == 2) { if (l.wgi_ntw == 4) { if (passes == 3) WGI(2, 4, 3, false); else WGI(2, 4, 1, false); }
                        if (l.wgi_ntw == 3) { if (passes == 3) WGI(2, 3, 3, false); else WGI(2, 3, 1, false); }
                        if (l.wgi_ntw == 2) { if (passes == 3) WGI(2, 2, 3, false); else WGI(2, 2, 1, false); } }
-        else         { if (l.wgi_ntw == 4) { if (passes == 3) WGI(4, 4, 3, false); else WGI(4, 4, 1, false); }
+        else         { if (l.wgi_ntw == 9) { if (passes == 3) WGI(4, 9, 3, false); else WGI(4, 9, 1, false); }
+                       if (l.wgi_ntw == 8) { if (passes == 3) WGI(4, 8, 3, false); else WGI(4, 8, 1, false); }
+                       if (l.wgi_ntw == 4) { if (passes == 3) WGI(4, 4, 3, false); else WGI(4, 4, 1, false); }
                        if (l.wgi_ntw == 3) { if (passes == 3) WGI(4, 3, 3, false); else WGI(4, 3, 1, false); }
                        if (l.wgi_ntw == 2) { if (passes == 3) WGI(4, 2, 3, false); else WGI(4, 2, 1, false); } }
     }

@@ -2,6 +2,7 @@
 // Mirrors slimdqn/networks/architectures/dqn.py:47-103 (cnn / fc branches) and the
 // (1+K)*A head view of slimdqn/networks/isdqn.py:34-41.
 #pragma once
+#include <cstdlib>
 #include <string.h>
 
 #include <string>
@@ -214,9 +215,15 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
             if (l.K % 64 == 0 && (l.is_u8 || l.cin_p % 16 == 0)) {
                 int ntw = (l.K % 256 == 0) ? 4 : (l.K % 192 == 0) ? 3 : (l.K % 128 == 0) ? 2 : 0;
                 if (l.K == 512) ntw = 2;
+                // 64 output channels and K <= 576: one workgroup owns every k' column (8 or 9 column tiles per
+                // wave), so each image pair is staged into LDS exactly once instead of once per column group
+                const bool wide = l.cout_p == 64 && !l.is_u8 && (l.K == 512 || l.K == 576);
+                if (wide) ntw = l.K / 64;
                 if (ntw) {
                     int ncg = l.K / (64 * ntw);
                     int G = (P.B * ncg + 255) / 256;
+                    if (wide) G = (P.B + 127) / 128;  // ~128 workgroups of two images: measured best (1: 2681, 2: 2806 steps/s)
+                    if (const char* e = getenv("ISDQN_WGI_G")) G = atoi(e);
                     if (G < 1) G = 1;
                     l.wgi_ntw = ntw;
                     l.wgi_G = G;

@@ -5,7 +5,7 @@ f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
 df = pd.read_csv(f).sort_values("Start_Timestamp")
 names = df.Kernel_Name.tolist()
 # last occurrence of the first-layer forward kernel marks a step start
-idx = [i for i, n in enumerate(names) if "conv_fwd_img_kernel<2, 2, true>" in n or "conv_fwd_img_kernel<2, 1, true>" in n]
+idx = [i for i, n in enumerate(names) if "conv_fwd_img_kernel<2, 2, true" in n or "conv_fwd_img_kernel<2, 1, true" in n]
 start = idx[-2]; end = idx[-1]
 t0 = df.iloc[start].Start_Timestamp
 for i in range(start, end):

@@ -4,7 +4,7 @@ import pandas as pd
 f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
 df = pd.read_csv(f).sort_values("Start_Timestamp").reset_index(drop=True)
 names = df.Kernel_Name.tolist()
-idx = [i for i, n in enumerate(names) if "conv_fwd_img_kernel<2, 2, true>" in n]
+idx = [i for i, n in enumerate(names) if "conv_fwd_img_kernel<2, 2, true" in n]
 print("n steps seen", len(idx))
 k = int(sys.argv[2]) if len(sys.argv) > 2 else -3
 start, end = idx[k], idx[k + 1]
