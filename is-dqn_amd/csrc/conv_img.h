@@ -30,6 +30,7 @@ struct ConvImgParams {
     int PP;                  // fp32 layers: pixel pitch in elements (cin_p + pad: spreads consecutive pixels over LDS banks)
     int plane_elems;         // bf16 elements of one precision plane of the image
     int ablate;              // profiling only (env ISDQN_ABLATE): 1 skip fill, 2 skip K loop, 4 skip epilogue
+    FastDiv d_chunk, d_Wp, d_R;  // fill index math: chunks per pixel (fp32) or per row (uint8), padded width, local rows
     long long* stamps;       // profiling only (isdqn_debug_set_stamps): [workgroup][8] s_memtime / s_memrealtime at phase boundaries
 };
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
     // ---------------- stage the input rows of this tile into LDS (zero border included) ----------------
     // FILL_BATCH chunk loads are issued back to back before the first one is consumed: a plain
     // load -> convert -> store loop is one L2/HBM round trip per iteration.
-    constexpr int FILL_BATCH = 8;
+    constexpr int FILL_BATCH = U8 ? 8 : 12;  // chunks in flight per thread: the 21x21x32 image (10.6 chunks) in ONE round trip
     if (p.ablate & 1) {
     } else if constexpr (U8) {
         // planar: img[c][lr][Wp], chunk = 8 consecutive padded columns
@@ -93,12 +94,13 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
                 const int c0 = cb + u * NTHR + tid;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
-                const int cx = cq % cpr, rest = cq / cpr;
-                const int lr = rest % p.R, c = rest / p.R;
+                uint32_t cx, rest, lr, c;
+                p.d_chunk.divmod((uint32_t)cq, rest, cx);
+                p.d_R.divmod(rest, c, lr);
                 int id = c == 0 ? fid[0] : c == 1 ? fid[1] : c == 2 ? fid[2] : fid[3];
                 if (c > 3) id = p.fs.frame_id(j, c);
-                p.fs.patch8_raw(on ? id : -1, row_base + lr, cx * 8 - g.pad, raw[u], sh[u]);
-                dst[u] = on ? ((c * p.R + lr) * p.Wp + cx * 8) : -1;
+                p.fs.patch8_raw(on ? id : -1, row_base + (int)lr, (int)cx * 8 - g.pad, raw[u], sh[u]);
+                dst[u] = on ? (((int)c * p.R + (int)lr) * p.Wp + (int)cx * 8) : -1;
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
@@ -121,12 +123,13 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
                 const int c0 = cb + u * NTHR + tid;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
-                const int cc = cq % cpp, pix = cq / cpp;
-                const int xp = pix % p.Wp, lr = pix / p.Wp;
-                const int iy = row_base + lr, ix = xp - g.pad;
+                uint32_t cc, pix, xp, lr;
+                p.d_chunk.divmod((uint32_t)cq, pix, cc);
+                p.d_Wp.divmod(pix, lr, xp);
+                const int iy = row_base + (int)lr, ix = (int)xp - g.pad;
                 const bool ok = on && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-                load8_aligned(ok ? p.in + ((((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + cc * 8) : zero_chunk(), v[u]);
-                dst[u] = on ? (pix * p.PP + cc * 8) : -1;
+                load8_aligned(ok ? p.in + ((((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + (int)cc * 8) : zero_chunk(), v[u]);
+                dst[u] = on ? ((int)pix * p.PP + (int)cc * 8) : -1;
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
@@ -448,11 +451,13 @@ struct ConvWgradImgParams {
     int in_plane;        // elements of one precision plane of the input image
     int PA, npix_pad;    // dz image: row pitch (elements), rows padded to a multiple of 32
     int dz_plane;        // elements of one precision plane of the dz image
+    FastDiv d_chunk, d_Wp, d_R, d_dzchunk;  // fill index math (see ConvImgParams)
 };
 
 template <bool U8, int PASSES>
 __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, const ConvGeom& g, const FrameSrc& fs,
-                                                 const float* in, int j, int row_base, int R, int Wp, int tid) {
+                                                 const float* in, int j, int row_base, int R, int Wp, int tid,
+                                                 const FastDiv& d_chunk, const FastDiv& d_Wp, const FastDiv& d_R) {
     constexpr int FILL_BATCH = 8;
     if constexpr (U8) {
         const int cpr = Wp / 8;
@@ -469,12 +474,13 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
                 const int c0 = cb + u * GEMM_THREADS + tid;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
-                const int cx = cq % cpr, rest = cq / cpr;
-                const int lr = rest % R, c = rest / R;
+                uint32_t cx, rest, lr, c;
+                d_chunk.divmod((uint32_t)cq, rest, cx);
+                d_R.divmod(rest, c, lr);
                 int id = c == 0 ? fid[0] : c == 1 ? fid[1] : c == 2 ? fid[2] : fid[3];
                 if (c > 3) id = fs.frame_id(j, c);
-                fs.patch8_raw(on ? id : -1, row_base + lr, cx * 8 - g.pad, raw[u], sh[u]);
-                dst[u] = on ? ((c * R + lr) * Wp + cx * 8) : -1;
+                fs.patch8_raw(on ? id : -1, row_base + (int)lr, (int)cx * 8 - g.pad, raw[u], sh[u]);
+                dst[u] = on ? (((int)c * R + (int)lr) * Wp + (int)cx * 8) : -1;
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
@@ -496,12 +502,13 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
                 const int c0 = cb + u * GEMM_THREADS + tid;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
-                const int cc = cq % cpp, pix = cq / cpp;
-                const int xp = pix % Wp, lr = pix / Wp;
-                const int iy = row_base + lr, ix = xp - g.pad;
+                uint32_t cc, pix, xp, lr;
+                d_chunk.divmod((uint32_t)cq, pix, cc);
+                d_Wp.divmod(pix, lr, xp);
+                const int iy = row_base + (int)lr, ix = (int)xp - g.pad;
                 const bool ok = on && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-                load8_aligned(ok ? in + ((((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + cc * 8) : zero_chunk(), v[u]);
-                dst[u] = on ? (pix * g.cin_p + cc * 8) : -1;
+                load8_aligned(ok ? in + ((((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + (int)cc * 8) : zero_chunk(), v[u]);
+                dst[u] = on ? ((int)pix * g.cin_p + (int)cc * 8) : -1;
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
@@ -577,10 +584,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const Conv
                     const int c0 = cb + u * GEMM_THREADS + tid;
                     const bool on = c0 < n_chunks;
                     const int cq = on ? c0 : 0;
-                    const int cc = cq % cpr, pix = cq / cpr;
-                    const bool ok = on && pix < g.npix;
-                    load8_aligned(ok ? p.dz + (((int64_t)j * g.npix + pix) * g.cout_p + cc * 8) : zero_chunk(), v[u]);
-                    dst[u] = on ? (pix * p.PA + cc * 8) : -1;
+                    uint32_t cc, pix;
+                    p.d_dzchunk.divmod((uint32_t)cq, pix, cc);
+                    const bool ok = on && (int)pix < g.npix;
+                    load8_aligned(ok ? p.dz + (((int64_t)j * g.npix + (int)pix) * g.cout_p + (int)cc * 8) : zero_chunk(), v[u]);
+                    dst[u] = on ? ((int)pix * p.PA + (int)cc * 8) : -1;
                 }
 #pragma unroll
                 for (int u = 0; u < FILL_BATCH; ++u) {
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const Conv
                 }
             }
         }
-        fill_input_image<U8, PASSES>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, tid);
+        fill_input_image<U8, PASSES>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, tid, p.d_chunk, p.d_Wp, p.d_R);
         __syncthreads();
 
         for (int ks = 0; ks < nsteps; ++ks) {
@@ -691,6 +699,7 @@ struct ConvDgradImgParams {
     float* part;         // [n_wg][3][cin_p]
     int n_img, T, Kc;    // taps per dim per class, K of a class = T*T*cout_p
     int Hd, Wd, PPd, bt; // padded dz image rows / cols, pixel pitch (elements), top/left border
+    FastDiv d_chunk, d_Wd, d_T;  // fill index math (chunks per pixel, padded width) and taps per axis of a class
     int dz_plane;
     int tiles_per_img;   // sum over classes of ceil(class pixels / 128)
     int cls_tile_start[5];
@@ -736,12 +745,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
                 const int c0 = cb + u * GEMM_THREADS + tid;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
-                const int cc = cq % cpp, pix = cq / cpp;
-                const int xp = pix % p.Wd, yp = pix / p.Wd;
-                const int oy = yp - p.bt, ox = xp - p.bt;
+                uint32_t cc, pix, xp, yp;
+                p.d_chunk.divmod((uint32_t)cq, pix, cc);
+                p.d_Wd.divmod(pix, yp, xp);
+                const int oy = (int)yp - p.bt, ox = (int)xp - p.bt;
                 const bool ok = on && oy >= 0 && oy < g.hout && ox >= 0 && ox < g.wout;
-                load8_aligned(ok ? p.dz + ((((int64_t)j * g.hout + oy) * g.wout + ox) * g.cout_p + cc * 8) : zero_chunk(), v[u]);
-                dst[u] = on ? (pix * p.PPd + cc * 8) : -1;
+                load8_aligned(ok ? p.dz + ((((int64_t)j * g.hout + oy) * g.wout + ox) * g.cout_p + (int)cc * 8) : zero_chunk(), v[u]);
+                dst[u] = on ? ((int)pix * p.PPd + (int)cc * 8) : -1;
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
@@ -795,7 +805,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
             const bool ok = (k < p.Kc) && (a_ci0[i] < g.cin_p);
             uint32_t jt, co;
             g.d_coutp.divmod(ok ? (uint32_t)k : 0u, jt, co);
-            const int jy = (int)jt / p.T, jx = (int)jt % p.T;
+            uint32_t jy_u, jx_u;
+            p.d_T.divmod(jt, jy_u, jx_u);
+            const int jy = (int)jy_u, jx = (int)jx_u;
             const int ky = py + g.stride * jy, kx = px + g.stride * jx;
             load8_aligned(ok ? p.W + ((int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + a_ci0[i]) : zero_chunk(), sa[slot][i]);
         }
@@ -840,7 +852,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
         kq = kq < k_last ? kq : k_last;
         uint32_t jt, co;
         g.d_coutp.divmod((uint32_t)kq, jt, co);
-        const int jy = (int)jt / p.T, jx = (int)jt % p.T;
+        uint32_t jy_u, jx_u;
+        p.d_T.divmod(jt, jy_u, jx_u);
+        const int jy = (int)jy_u, jx = (int)jx_u;
         const int tap_off = -(jy * p.Wd + jx) * p.PPd + (int)co;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {

@@ -898,6 +898,9 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     ip.scale = l.is_u8 ? (1.0f / 255.0f) : 1.0f;
     ip.act = act; ip.z = z; ip.n_img = n_img; ip.z_img = z_img;
     ip.tiles_per_img = ceil_div(l.npix, 128);
+    ip.d_chunk = FastDiv((uint32_t)(l.is_u8 ? ip.Wp / 8 : l.cin_p / 8));
+    ip.d_Wp = FastDiv((uint32_t)ip.Wp);
+    ip.d_R = FastDiv((uint32_t)ip.R);
     ip.stamps = (g_stamp_layer >= 0 && strcmp(l.name, g_stamp_name) == 0) ? g_stamps : nullptr;
     {
         const char* e = getenv("ISDQN_ABLATE");
@@ -1126,6 +1129,10 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
     wp.dz_plane = wp.npix_pad * wp.PA;
     const int lds = ((passes >= 2 ? 2 : 1) * wp.dz_plane + (passes >= 3 ? 2 : 1) * wp.in_plane) * 2;
     if (lds > 150 * 1024 || (l.is_u8 && (l.win < 8 || l.cin > 16))) return ISDQN_OK;
+    wp.d_chunk = FastDiv((uint32_t)(l.is_u8 ? Wp / 8 : l.cin_p / 8));
+    wp.d_Wp = FastDiv((uint32_t)Wp);
+    wp.d_R = FastDiv((uint32_t)wp.R);
+    wp.d_dzchunk = FastDiv((uint32_t)(l.cout_p / 8));
     wp.dz = dz; wp.in = act_in;
     wp.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win};
     wp.slabs = slabs;
@@ -1181,6 +1188,9 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
     dp.Wd = dp.bt + (l.wout > need_w ? l.wout : need_w);
     dp.PPd = l.cout_p + 8;
     dp.dz_plane = dp.Hd * dp.Wd * dp.PPd;
+    dp.d_chunk = FastDiv((uint32_t)(l.cout_p / 8));
+    dp.d_Wd = FastDiv((uint32_t)dp.Wd);
+    dp.d_T = FastDiv((uint32_t)dp.T);
     dp.n_classes = l.stride * l.stride;
     int acc = 0;
     for (int c = 0; c < dp.n_classes; ++c) {

@@ -11,7 +11,8 @@ import os
 from ctypes import POINTER, c_char, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libisdqn_hip.so")
+# ISDQN_HIP_LIB: development override (A/B timing of two builds inside one gpurun call); still a HIP build, never a fallback
+LIB_PATH = os.environ.get("ISDQN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libisdqn_hip.so")
 
 OK = 0
 ERR_CAPACITY, ERR_NEGATIVE, ERR_SHAPE, ERR_EMPTY, ERR_RANGE, ERR_UNSUPPORTED, ERR_HIP, ERR_ARG = range(-1, -9, -1)
