@@ -73,6 +73,69 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
     const int oy_min = p0 / g.wout;
     const int row_base = oy_min * g.stride - g.pad;  // global input row of local row 0
 
+    // Epilogue parameters (bias, gamma, beta of up to 64 channels): one float per thread is requested now and parked
+    // in LDS once the image fill has drained, so the epilogue neither waits on global memory nor do the values
+    // occupy registers through the K loop (a few VGPRs decide whether two workgroups share a CU).
+    const int grp = lane >> 4;
+    __shared__ __attribute__((aligned(16))) float s_par[3][64];
+    float par_v = 0.f;
+    {
+        const int which = tid >> 6, ch = tid & 63;
+        const float* src = which == 0 ? p.bias : which == 1 ? p.gamma : p.beta;
+        const bool ok = tid < 192 && ch < g.cout_p && src != nullptr;
+        par_v = *(const ISDQN_GLOBAL float*)(ok ? src + ch : zero_chunk());
+    }
+
+    const int nsteps = (g.K + GEMM_BK - 1) / GEMM_BK;
+    const int k_last = g.K - 8;  // last valid chunk start (weights are zero-filled past K, B only has to stay finite)
+    // ---------------- weight K-slice staging (A operand, ROW image), as in the generic engine ----------------
+    constexpr int A_PER = (GA::CHUNKS + NTHR - 1) / NTHR;
+    int a_row[A_PER], a_var[A_PER], a_lds[A_PER];
+    bool a_on[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        int c = tid + i * NTHR;
+        a_on[i] = c < GA::CHUNKS;
+        if (!a_on[i]) c = 0;
+        a_row[i] = c >> 2;
+        a_var[i] = (c & 3) * 8;
+        a_lds[i] = (c >> 2) * GA::PITCH + (c & 3) * 8;
+    }
+    // Weight slices are fetched PF steps ahead into a ring of register sets: with one workgroup per CU nothing
+    // else hides the L2 round trip, and one K step of MFMA work is shorter than it.
+    constexpr int PF = 4;
+    float sa[PF][A_PER][8];
+    auto fetch = [&](int slot, int k) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) p.W.load(a_row[i], k + a_var[i], sa[slot][i]);
+    };
+    auto stash = [&](int slot, int stage) {
+        __bf16* a_hi = a_stage + stage * T::A_STAGE;
+        __bf16* a_lo = a_hi + GA::ELEMS;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            if (!a_on[i]) continue;
+            bf16x8 hi, lo;
+            if constexpr (PASSES >= 2) {
+                split8(sa[slot][i], hi, lo);
+                *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
+            } else {
+                round8(sa[slot][i], hi);
+            }
+            *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
+        }
+    };
+
+    const int nsteps_p = (nsteps + PF - 1) / PF * PF;
+    const int rot = (p.ablate & 16) ? 0 : (int)((blockIdx.x >> 3) % (unsigned)nsteps);
+    auto slice = [&](int s) {  // K step handled at loop position s; positions past nsteps read zeros
+        const int k = s + rot;
+        return s < nsteps ? (k >= nsteps ? k - nsteps : k) : nsteps_p;
+    };
+    // the first PF weight slices are requested BEFORE the image fill: they travel under it
+#pragma unroll
+    for (int d = 0; d < PF; ++d) fetch(d, slice(d) * GEMM_BK);
+
     // ---------------- stage the input rows of this tile into LDS (zero border included) ----------------
     // FILL_BATCH chunk loads are issued back to back before the first one is consumed: a plain
     // load -> convert -> store loop is one L2/HBM round trip per iteration.
@@ -157,45 +220,6 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
         const int lx0 = ox * g.stride;                     // padded column of tap kx = 0
         b_org[nt] = U8 ? (ly0 * p.Wp + lx0) : (ly0 * p.Wp + lx0) * p.PP;
     }
-    const int grp = lane >> 4;
-
-    // ---------------- weight K-slice staging (A operand, ROW image), as in the generic engine ----------------
-    constexpr int A_PER = (GA::CHUNKS + NTHR - 1) / NTHR;
-    int a_row[A_PER], a_var[A_PER], a_lds[A_PER];
-    bool a_on[A_PER];
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-        int c = tid + i * NTHR;
-        a_on[i] = c < GA::CHUNKS;
-        if (!a_on[i]) c = 0;
-        a_row[i] = c >> 2;
-        a_var[i] = (c & 3) * 8;
-        a_lds[i] = (c >> 2) * GA::PITCH + (c & 3) * 8;
-    }
-    // Weight slices are fetched PF steps ahead into a ring of register sets: with one workgroup per CU nothing
-    // else hides the L2 round trip, and one K step of MFMA work is shorter than it.
-    constexpr int PF = 4;
-    float sa[PF][A_PER][8];
-    auto fetch = [&](int slot, int k) {
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) p.W.load(a_row[i], k + a_var[i], sa[slot][i]);
-    };
-    auto stash = [&](int slot, int stage) {
-        __bf16* a_hi = a_stage + stage * T::A_STAGE;
-        __bf16* a_lo = a_hi + GA::ELEMS;
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            if (!a_on[i]) continue;
-            bf16x8 hi, lo;
-            if constexpr (PASSES >= 2) {
-                split8(sa[slot][i], hi, lo);
-                *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
-            } else {
-                round8(sa[slot][i], hi);
-            }
-            *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
-        }
-    };
 
     f32x4 acc[MTW][NT];
 #pragma unroll
@@ -203,8 +227,6 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = (g.K + GEMM_BK - 1) / GEMM_BK;
-    const int k_last = g.K - 8;  // last valid chunk start (weights are zero-filled past K, B only has to stay finite)
 
     // Fragments of one K step: MTW weight tiles and NT pixel tiles, each hi (+ lo).  Two sets alternate so that the
     // ds_reads of step s+1 are in flight while the MFMAs of step s run (one wave per SIMD: nothing else overlaps them).
@@ -269,16 +291,9 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
     // (rows are K*4 bytes apart), so the workgroups of one XCD, started together, would all pull the same few L2
     // lines -- one or two L2 channels -- at the same moment.  Each workgroup therefore walks the K steps from its
     // own starting slice; workgroups b, b+8, b+16, ... share an XCD, hence the rotation by b/8.
-    const int nsteps_p = (nsteps + PF - 1) / PF * PF;
-    const int rot = (p.ablate & 16) ? 0 : (int)((blockIdx.x >> 3) % (unsigned)nsteps);
-    auto slice = [&](int s) {  // K step handled at loop position s; positions past nsteps read zeros
-        const int k = s + rot;
-        return s < nsteps ? (k >= nsteps ? k - nsteps : k) : nsteps_p;
-    };
     static_assert(PF % 2 == 0, "the fragment sets alternate with the step parity");
     Frags fr[2];
-#pragma unroll
-    for (int d = 0; d < PF; ++d) fetch(d, slice(d) * GEMM_BK);
+    if (tid < 192) s_par[tid >> 6][tid & 63] = par_v;
     stash(0, 0);
     __syncthreads();  // image and first weight slice visible
     ISDQN_STAMP(2);
@@ -308,15 +323,15 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
     // ---------------- epilogue: bias + LayerNorm over channels + ReLU (same math as ConvFwd::epilogue) -------------
     float bi[MTW][4], ga[MTW][4], be[MTW][4];
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int ch = (mt0 + mt) * 16 + grp * 4 + r;
-            bool ok = ch < g.cout;
-            bi[mt][r] = ok ? p.bias[ch] : 0.f;
-            ga[mt][r] = (ok && p.gamma) ? p.gamma[ch] : 1.f;
-            be[mt][r] = (ok && p.gamma) ? p.beta[ch] : 0.f;
-        }
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int ch0 = ((mt0 + mt) * 16 + grp * 4) & 63;
+        const float4 b4 = *reinterpret_cast<const float4*>(&s_par[0][ch0]);
+        const float4 g4 = *reinterpret_cast<const float4*>(&s_par[1][ch0]);
+        const float4 e4 = *reinterpret_cast<const float4*>(&s_par[2][ch0]);
+        bi[mt][0] = b4.x; bi[mt][1] = b4.y; bi[mt][2] = b4.z; bi[mt][3] = b4.w;
+        ga[mt][0] = g4.x; ga[mt][1] = g4.y; ga[mt][2] = g4.z; ga[mt][3] = g4.w;
+        be[mt][0] = e4.x; be[mt][1] = e4.y; be[mt][2] = e4.z; be[mt][3] = e4.w;
+    }
     const float inv_c = 1.0f / (float)g.cout;
     float zv[NT][MTW][4], s1[NT], s2[NT];
 #pragma unroll
@@ -732,6 +747,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
     const int n_cls_pix = Ha * Wb;
     const int py = (cy + g.pad) % g.stride, px = (cx + g.pad) % g.stride;
 
+    // LayerNorm parameters of the layer below for the epilogue: requested now (one float per thread), parked in LDS
+    // after the fill (see conv_fwd_img_kernel)
+    __shared__ __attribute__((aligned(16))) float s_gb[2][64];
+    float par_v = 0.f;
+    {
+        const int which = tid >> 6, ch = tid & 63;
+        const float* src = which == 0 ? p.gamma : p.beta;
+        const bool ok = tid < 128 && ch < g.cin_p && p.gamma != nullptr;
+        par_v = *(const ISDQN_GLOBAL float*)(ok ? src + ch : zero_chunk());
+    }
+
     // ---- dz image of this sample into LDS (zero border) ----
     {
         constexpr int FILL_BATCH = 8;
@@ -902,6 +928,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
     Frags fr[2];
 #pragma unroll
     for (int d = 0; d < PF; ++d) fetch(d, slice(d) * GEMM_BK);
+    if (tid < 128) s_gb[tid >> 6][tid & 63] = par_v;
     stash(0, 0);
     __syncthreads();
     read_frags(0, slice(0), fr[0]);
@@ -919,17 +946,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
 
     // ---- epilogue: LayerNorm + ReLU backward of the layer below, per input pixel (column) ----
     float ga[MT][4], be[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ch0 = (mt * 16 + grp * 4) & 63;
+        const float4 g4 = *reinterpret_cast<const float4*>(&s_gb[0][ch0]);
+        const float4 e4 = *reinterpret_cast<const float4*>(&s_gb[1][ch0]);
+        ga[mt][0] = g4.x; ga[mt][1] = g4.y; ga[mt][2] = g4.z; ga[mt][3] = g4.w;
+        be[mt][0] = e4.x; be[mt][1] = e4.y; be[mt][2] = e4.z; be[mt][3] = e4.w;
+    }
     float dg[MT][4], db[MT][4], dbias[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ch = mt * 16 + grp * 4 + r;
-            const bool ok = ch < p.c_in;
-            ga[mt][r] = (ok && p.gamma) ? p.gamma[ch] : 1.f;
-            be[mt][r] = (ok && p.gamma) ? p.beta[ch] : 0.f;
-            dg[mt][r] = db[mt][r] = dbias[mt][r] = 0.f;
-        }
+        for (int r = 0; r < 4; ++r) dg[mt][r] = db[mt][r] = dbias[mt][r] = 0.f;
     const float inv_c = 1.f / (float)p.c_in;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
