@@ -39,7 +39,16 @@ struct ConvImgTraits {
     static constexpr int BM = MT * 16;
     static constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
     static constexpr int B_PLANES = (PASSES >= 3) ? 2 : 1;
-    using GA = TileGeom<BM, false>;
+    // Weight stage image [BM rows][32 k], row pitch 48 elements = 96 bytes.  ds_read_b128 is served in 16-lane groups
+    // ({0-3,12-15,20-27}, ...), each lane covering 4 of the 64 banks; with fragment lane l reading row l&15, chunk
+    // l>>4, the 16 lanes of a group hit 16 distinct bank quads exactly when (pitch/16) = 2 (mod 4).  The generic
+    // engine's 80-byte pitch gives 2-way conflicts on these reads, which the four waves of the workgroup (all reading
+    // the SAME weight fragments) pay four times per K step.
+    struct GA {
+        static constexpr int PITCH = 48;
+        static constexpr int ELEMS = BM * PITCH;
+        static constexpr int CHUNKS = BM * (GEMM_BK / 8);
+    };
     static constexpr int A_STAGE = A_PLANES * GA::ELEMS;
 };
 
@@ -438,7 +447,7 @@ static inline int conv_img_geometry(const ConvGeom& g, bool u8, int stack, int b
         Wp = (g.wout - 1) * g.stride + g.ksz;           // = win + pad_lo + pad_hi
         plane_elems = R * Wp * (pixel_pitch ? pixel_pitch : g.cin_p);
     }
-    const int a_stage = a_planes * (mt * 16) * (GEMM_BK + 8);
+    const int a_stage = a_planes * (mt * 16) * 48;  // ConvImgTraits::GA::PITCH
     return (2 * a_stage + b_planes * plane_elems) * 2;
 }
 

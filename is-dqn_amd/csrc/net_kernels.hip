@@ -1186,7 +1186,8 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
     const int need_h = (l.hin - 1 + l.pad) / l.stride + 1, need_w = (l.win - 1 + l.pad) / l.stride + 1;
     dp.Hd = dp.bt + (l.hout > need_h ? l.hout : need_h);
     dp.Wd = dp.bt + (l.wout > need_w ? l.wout : need_w);
-    dp.PPd = l.cout_p + 8;
+    // pixel pitch with (pitch bytes / 16) = 2 (mod 4): conflict-free ds_read_b128 of 16 consecutive pixels (conv_img.h)
+    dp.PPd = l.cout_p + ((16 - l.cout_p % 32) + 32) % 32;
     dp.dz_plane = dp.Hd * dp.Wd * dp.PPd;
     dp.d_chunk = FastDiv((uint32_t)(l.cout_p / 8));
     dp.d_Wd = FastDiv((uint32_t)dp.Wd);

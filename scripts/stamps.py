@@ -52,6 +52,6 @@ s2 = st.cpu().numpy().reshape(nwg, 8)
 g = len(s)
 rows = s2[g:2 * g]
 if rows[:, 0].any():
-    dd = np.diff(rows[:, :5], axis=1)
-    for i, n in enumerate(["A frag reads", "tap calc + B reads + MFMA issue", "stash (vmcnt wait + cvt + ds_write)", "barrier"]):
+    dd = np.diff(rows[:, :6], axis=1)
+    for i, n in enumerate(["fetch issue", "stash (vmcnt wait + cvt + ds_write)", "barrier (lgkmcnt(0) + s_barrier)", "read_frags issue", "24 MFMAs issue"]):
         print(f"  step: {n:40s} median {np.median(dd[:, i]):7.0f} cyc  p90 {np.percentile(dd[:, i], 90):7.0f}")
