@@ -41,9 +41,12 @@ struct FastDiv {
             sh = p - 32;
         }
     }
+    // Branch-free on the device: a `d == 1 ? n : ...` expression becomes a scalar branch, which splits the K-loop
+    // bodies that use it into several basic blocks and stops the scheduler from interleaving their pieces.
     __host__ __device__ __forceinline__ uint32_t div(uint32_t n) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-        return d == 1 ? n : (__umulhi(n, m) >> sh);
+        const uint32_t q = __umulhi(n, m) >> sh;
+        return d == 1 ? n : q;
 #else
         return d == 1 ? n : (uint32_t)((((uint64_t)n * m) >> 32) >> sh);
 #endif

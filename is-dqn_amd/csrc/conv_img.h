@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
         __bf16* a_lo = a_hi + GA::ELEMS;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            if (!a_on[i]) continue;
+            if (GA::CHUNKS % NTHR != 0 && !a_on[i]) continue;  // (whole multiples: no guard, no branch in the K loop)
             bf16x8 hi, lo;
             if constexpr (PASSES >= 2) {
                 split8(sa[slot][i], hi, lo);
@@ -300,26 +300,40 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
     // (rows are K*4 bytes apart), so the workgroups of one XCD, started together, would all pull the same few L2
     // lines -- one or two L2 channels -- at the same moment.  Each workgroup therefore walks the K steps from its
     // own starting slice; workgroups b, b+8, b+16, ... share an XCD, hence the rotation by b/8.
-    static_assert(PF % 2 == 0, "the fragment sets alternate with the step parity");
+    static_assert(PF % 2 == 0 && PF >= 4, "the fragment sets alternate with the step parity; steps 0..3 are pre-fetched");
     Frags fr[2];
     if (tid < 192) s_par[tid >> 6][tid & 63] = par_v;
-    stash(0, 0);
-    __syncthreads();  // image and first weight slice visible
+    stash(0, 0);  // steps 0 and 1 fill the two LDS stages; their ring slots take steps PF and PF+1
+    stash(1, 1);
+    fetch(0, slice(PF) * GEMM_BK);
+    fetch(1, slice(PF + 1) * GEMM_BK);
+    __syncthreads();  // image and the first two weight slices visible
     ISDQN_STAMP(2);
     if (!(p.ablate & 2)) {
-        // Step s: weights of step s+1 go to LDS stage (s+1)&1 first (its last readers finished before the barrier
-        // that ended step s-1), then -- after the barrier -- the fragments of step s+1 are requested and the MFMAs
-        // of step s run on the set read one step earlier.
+        // One barrier per K step, and everything between two barriers is independent, so the compiler is free to
+        // interleave it: the fragment reads of step s+1 (stage (s+1)&1, written during step s-1), the MFMAs of step s
+        // (fragments read during step s-1), the conversion of slice s+2 into stage s&1 (whose readers finished before
+        // the last barrier) and the request for slice s+2+PF.
         read_frags(0, slice(0), fr[0]);
         for (int s0 = 0; s0 < nsteps_p; s0 += PF) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {  // slot of step s is s % PF = u; it was stashed during step s-1
+            for (int u = 0; u < PF; ++u) {
                 const int s = s0 + u;
-                fetch(u, slice(s + PF) * GEMM_BK);
-                stash((u + 1) % PF, (s + 1) & 1);
-                __syncthreads();                                   // stage (s+1)&1 complete
-                read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);  // in flight during the MFMAs below
+                read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
                 mfma_step(fr[u & 1]);
+                stash((u + 2) % PF, s & 1);
+                fetch((u + 2) % PF, slice(s + 2 + PF) * GEMM_BK);
+                // Issue order for the block: a 16x16x32 MFMA occupies the matrix pipe for 16 cycles but the issue port
+                // for 8, so every MFMA is followed by one LDS operation or two vector instructions of the other
+                // pieces; left alone, the compiler emits the MFMAs back to back and the rest serially behind them.
+                constexpr int N_MFMA = MTW * NT * (PASSES >= 3 ? 3 : PASSES);
+#pragma unroll
+                for (int i = 0; i < N_MFMA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    if (i < N_MFMA / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read/write
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // 2 VALU
+                }
+                __syncthreads();
             }
         }
     }
@@ -852,7 +866,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
         __bf16* a_lo = a_hi + GA::ELEMS;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            if (!a_on[i]) continue;
+            if (GA::CHUNKS % GEMM_THREADS != 0 && !a_on[i]) continue;  // (whole multiples: no guard, no branch in the K loop)
             bf16x8 hi, lo;
             if constexpr (PASSES >= 2) {
                 split8(sa[slot][i], hi, lo);
