@@ -1442,14 +1442,14 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         else rc = cols == 1 ? launch_hc(&head_chain_kernel<1, 1>, 3) : cols == 2 ? launch_hc(&head_chain_kernel<1, 2>, 4)
                                                                                   : launch_hc(&head_chain_kernel<1, 4>, 5);
         if (rc) return rc;
-        // loss / head-bias reductions and the head's weight gradient leave the critical path
-        if (ss) {
-            rc = chain(ss, st, wst);
-            if (rc) return rc;
+        // The loss / head-bias reductions and the head's weight gradient leave the critical path: with a weight-
+        // gradient stream they are enqueued there behind the first fork the backward pass makes anyway (every fork
+        // costs the main stream a dependency bubble, so none is spent on these two small kernels alone).
+        if (!ss) {
+            hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p,
+                               losses, loss_accum, ws + P.dbh_off, (int*)nullptr, cfg->adam_b1, cfg->adam_b2, adam_consts);
+            ISDQN_HIP_CHECK(hipGetLastError());
         }
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, wst, loss_part, dbh_part, n_blk, B, K, P.nha_p,
-                           losses, loss_accum, ws + P.dbh_off, (int*)nullptr, cfg->adam_b1, cfg->adam_b2, adam_consts);
-        ISDQN_HIP_CHECK(hipGetLastError());
     } else {
         hipLaunchKernelGGL(td_kernel, dim3(n_blk), dim3(256), 2 * TD_ROWS * K * sizeof(float), st, ws + P.q_off, B, K,
                            P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n,
@@ -1475,6 +1475,18 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     const float* dz_cur = ws + P.dout_off;  // gradient w.r.t. the current layer's pre-activation output
     int dz_ld = P.nha_p;
     bool dz_fused = false;  // dz of layer i was already produced by the fused data gradient of layer i+1
+    bool head_deferred = hc_S && ss;  // loss_finalize + head weight gradient still to be enqueued on the side stream
+    auto run_head_deferred = [&](hipStream_t s2) -> int {
+        if (!head_deferred) return ISDQN_OK;
+        head_deferred = false;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s2, loss_part, dbh_part, n_blk, B, K, P.nha_p, losses,
+                           loss_accum, ws + P.dbh_off, (int*)nullptr, cfg->adam_b1, cfg->adam_b2, adam_consts);
+        ISDQN_HIP_CHECK(hipGetLastError());
+        MatSrc A{ws + P.dout_off, P.nha_p, B, head.out_p, 1};
+        MatSrc Bm{ws + hid.act_off, head.in_p, B, head.in_p, 1};
+        return plain_big<true, true>(x3, A, nullptr, 0, Bm, ws + head.gw_off, head.in_p, head.out_p, head.in_p, B,
+                                     head.gw_slabs, head.w_size, s2);
+    };
     for (int i = P.n_layers - 1; i >= 0; --i) {
         const Layer& l = P.L[i];
         const float* act_in = i > 0 ? ws + P.L[i - 1].act_off : nullptr;
@@ -1517,6 +1529,8 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         const bool fork_after_dgrad = wg_on_side && l.kind == 1;
         if (wg_on_side && !fork_after_dgrad) {  // dz of this layer is final on the main stream
             rc = chain(ss, st, lws);
+            if (rc) return rc;
+            rc = run_head_deferred(lws);
             if (rc) return rc;
         }
         // data gradient for the layer below first: it reads this layer's weights, which the fused-Adam
@@ -1573,9 +1587,15 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         if (fork_after_dgrad) {  // dz is final AND the data gradient (which reads W) is enqueued: an in-place
             rc = chain(ss, st, lws);  // fused-Adam update on the side stream cannot overtake it
             if (rc) return rc;
+            rc = run_head_deferred(lws);
+            if (rc) return rc;
         }
         int w_slabs;
         bool fused_adam = false;
+        if (head_chained && ss) {  // enqueued by run_head_deferred()
+            add_entry(l.w_off, l.w_size, ws + l.gw_off, effective_splits(B, l.gw_slabs), l.w_size);
+            continue;
+        }
         if (l.kind == 0) {
             int img_slabs = 0;
             rc = conv_wgrad_img(l, x3, in, act_in, dz_cur, ws + l.gw_off, B, lws, &img_slabs);
@@ -1617,6 +1637,10 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         if (!fused_adam) add_entry(l.w_off, l.w_size, ws + l.gw_off, w_slabs, l.w_size);
     }
     tab.total_blocks = blocks;
+    if (head_deferred) {  // no layer forked: keep the two kernels in line
+        rc = run_head_deferred(st);
+        if (rc) return rc;
+    }
     if (ss) {  // all weight gradients done before Adam (and before the next call touches the workspace)
         rc = chain(ss, wst, st);
         if (rc) return rc;
