@@ -745,8 +745,10 @@ struct ConvDgradImgParams {
     int n_classes;
 };
 
+// (second launch-bound: two waves per SIMD, i.e. at most 256 registers -- the kernel sits right at that edge and two
+// workgroups per CU, its own or a weight-gradient one, are worth more than the last two registers)
 template <int MT, int PASSES>
-__global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const ConvDgradImgParams p) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const ConvDgradImgParams p) {
     constexpr int NT = 2;
     constexpr int BM = MT * 16;
     constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
@@ -780,6 +782,65 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
         const bool ok = tid < 128 && ch < g.cin_p && p.gamma != nullptr;
         par_v = *(const ISDQN_GLOBAL float*)(ok ? src + ch : zero_chunk());
     }
+
+    const int nsteps = (p.Kc + GEMM_BK - 1) / GEMM_BK;
+    const int k_last = p.Kc - 8;
+    // ---- weight K-slice staging: TR image [32 k][BM ci], chunk = 8 consecutive ci of one (tap, co) ----
+    constexpr int A_PER = GA::PER_THREAD;
+    int a_ci0[A_PER], a_kk[A_PER], a_lds[A_PER];
+    bool a_on[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        int c = tid + i * GEMM_THREADS;
+        a_on[i] = c < GA::CHUNKS;
+        if (!a_on[i]) c = 0;
+        const int kk = c / (BM / 8), rc = c % (BM / 8);
+        a_ci0[i] = rc * 8; a_kk[i] = kk;
+        a_lds[i] = kk * GA::PITCH + rc * 8;
+    }
+    constexpr int PF = 4;  // weight slices in flight (register ring), as in conv_fwd_img_kernel
+    float sa[PF][A_PER][8];
+    auto fetch = [&](int slot, int k0) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int k = k0 + a_kk[i];
+            const bool ok = (k < p.Kc) && (a_ci0[i] < g.cin_p);
+            uint32_t jt, co;
+            g.d_coutp.divmod(ok ? (uint32_t)k : 0u, jt, co);
+            uint32_t jy_u, jx_u;
+            p.d_T.divmod(jt, jy_u, jx_u);
+            const int jy = (int)jy_u, jx = (int)jx_u;
+            const int ky = py + g.stride * jy, kx = px + g.stride * jx;
+            load8_aligned(ok ? p.W + ((int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + a_ci0[i]) : zero_chunk(), sa[slot][i]);
+        }
+    };
+    auto stash = [&](int slot, int stage) {
+        __bf16* a_hi = a_stage + stage * A_STAGE;
+        __bf16* a_lo = a_hi + GA::ELEMS;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            if (GA::CHUNKS % GEMM_THREADS != 0 && !a_on[i]) continue;  // (whole multiples: no guard, no branch in the K loop)
+            bf16x8 hi, lo;
+            if constexpr (PASSES >= 2) {
+                split8(sa[slot][i], hi, lo);
+                *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
+            } else {
+                round8(sa[slot][i], hi);
+            }
+            *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
+        }
+    };
+
+    // K-step order of this workgroup (workgroups of one XCD start at different slices) and the first PF weight
+    // slices, requested before the image fill so that they travel under it
+    const int nsteps_p = (nsteps + PF - 1) / PF * PF;
+    const int rot = (int)((blockIdx.x >> 3) % (unsigned)nsteps);
+    auto slice = [&](int s) {
+        const int k = s + rot;
+        return s < nsteps ? (k >= nsteps ? k - nsteps : k) : nsteps_p;
+    };
+#pragma unroll
+    for (int d = 0; d < PF; ++d) fetch(d, slice(d) * GEMM_BK);
 
     // ---- dz image of this sample into LDS (zero border) ----
     {
@@ -832,60 +893,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
         b_org[nt] = ((oyb + p.bt) * p.Wd + oxb + p.bt) * p.PPd;
     }
 
-    // ---- weight K-slice staging: TR image [32 k][BM ci], chunk = 8 consecutive ci of one (tap, co) ----
-    constexpr int A_PER = GA::PER_THREAD;
-    int a_ci0[A_PER], a_kk[A_PER], a_lds[A_PER];
-    bool a_on[A_PER];
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-        int c = tid + i * GEMM_THREADS;
-        a_on[i] = c < GA::CHUNKS;
-        if (!a_on[i]) c = 0;
-        const int kk = c / (BM / 8), rc = c % (BM / 8);
-        a_ci0[i] = rc * 8; a_kk[i] = kk;
-        a_lds[i] = kk * GA::PITCH + rc * 8;
-    }
-    constexpr int PF = 4;  // weight slices in flight (register ring), as in conv_fwd_img_kernel
-    float sa[PF][A_PER][8];
-    auto fetch = [&](int slot, int k0) {
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const int k = k0 + a_kk[i];
-            const bool ok = (k < p.Kc) && (a_ci0[i] < g.cin_p);
-            uint32_t jt, co;
-            g.d_coutp.divmod(ok ? (uint32_t)k : 0u, jt, co);
-            uint32_t jy_u, jx_u;
-            p.d_T.divmod(jt, jy_u, jx_u);
-            const int jy = (int)jy_u, jx = (int)jx_u;
-            const int ky = py + g.stride * jy, kx = px + g.stride * jx;
-            load8_aligned(ok ? p.W + ((int64_t)co * g.K + (ky * g.ksz + kx) * g.cin_p + a_ci0[i]) : zero_chunk(), sa[slot][i]);
-        }
-    };
-    auto stash = [&](int slot, int stage) {
-        __bf16* a_hi = a_stage + stage * A_STAGE;
-        __bf16* a_lo = a_hi + GA::ELEMS;
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            if (GA::CHUNKS % GEMM_THREADS != 0 && !a_on[i]) continue;  // (whole multiples: no guard, no branch in the K loop)
-            bf16x8 hi, lo;
-            if constexpr (PASSES >= 2) {
-                split8(sa[slot][i], hi, lo);
-                *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
-            } else {
-                round8(sa[slot][i], hi);
-            }
-            *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
-        }
-    };
-
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = (p.Kc + GEMM_BK - 1) / GEMM_BK;
-    const int k_last = p.Kc - 8;
     struct Frags {
         bf16x8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
     };
@@ -939,31 +952,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_dgrad_img_kernel(const Conv
         }
     }
 
-    // straight-line main loop (see conv_fwd_img_kernel): register ring of PF slices, fragments of step s+1 read
-    // while the MFMAs of step s run; workgroups of one XCD start at different slices
-    static_assert(PF % 2 == 0, "the fragment sets alternate with the step parity");
-    const int nsteps_p = (nsteps + PF - 1) / PF * PF;
-    const int rot = (int)((blockIdx.x >> 3) % (unsigned)nsteps);
-    auto slice = [&](int s) {
-        const int k = s + rot;
-        return s < nsteps ? (k >= nsteps ? k - nsteps : k) : nsteps_p;
-    };
+    // main loop: one barrier per K step, independent pieces between barriers (see conv_fwd_img_kernel)
+    static_assert(PF % 2 == 0 && PF >= 4, "the fragment sets alternate with the step parity; steps 0..3 are pre-fetched");
     Frags fr[2];
-#pragma unroll
-    for (int d = 0; d < PF; ++d) fetch(d, slice(d) * GEMM_BK);
     if (tid < 128) s_gb[tid >> 6][tid & 63] = par_v;
     stash(0, 0);
+    stash(1, 1);
+    fetch(0, slice(PF) * GEMM_BK);
+    fetch(1, slice(PF + 1) * GEMM_BK);
     __syncthreads();
     read_frags(0, slice(0), fr[0]);
     for (int s0 = 0; s0 < nsteps_p; s0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int s = s0 + u;
-            fetch(u, slice(s + PF) * GEMM_BK);
-            stash((u + 1) % PF, (s + 1) & 1);
-            __syncthreads();
             read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
             mfma_step(fr[u & 1]);
+            stash((u + 2) % PF, s & 1);
+            fetch((u + 2) % PF, slice(s + 2 + PF) * GEMM_BK);
+            constexpr int N_MFMA = MT * NT * (PASSES >= 3 ? 3 : PASSES);
+#pragma unroll
+            for (int i = 0; i < N_MFMA; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                if (i < N_MFMA / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read/write
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // 2 VALU
+            }
+            __syncthreads();
         }
     }
 
