@@ -54,6 +54,24 @@ def algorithmic_flops_per_step(B, K, A):
     return 2 * mac * 2 * B + 2 * (2 * mac - mac_conv0) * B
 
 
+def measured_traffic(workload, precision):
+    """HBM bytes per step from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
+    correction applied; collected by hand with the recipe in profiles/round1/README.md and committed as JSON): counters
+    cannot be read from inside this process, so this is the last committed measurement for the same workload and
+    precision, or null when there is none."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"{workload}_hbm_traffic_*.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == workload and d.get("precision") == precision:
+            best = d
+    return None if best is None else float(best["hbm_bytes_per_step_corrected"])
+
+
 class Replica:
     """One independent (seed) replica of the training state on one GPU."""
 
@@ -250,7 +268,7 @@ def main():
                        "launch": f"hipGraph x{S} steps" if rep.graphed is not None else "eager", "replicas": world, "parallelism": f"independent-seed replicas x{world}"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(args.workload, args.precision),
                 "kernel": "replay-sample -> Bellman-update step (all launches of one step; HIP-event time per step)",
                 "algorithmic_bytes_per_step": bytes_step, "device_ms_per_step_avg": dev_ms_avg,
                 "host_issue_ms_per_step": t_issue / args.steps * 1e3,
