@@ -1095,11 +1095,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
 
 // Deterministic reduction of per-workgroup partial rows: out[c] = sum_r part[r][c].  One workgroup per 8
 // columns; 32 row-lanes per column stride over the rows with 8 independent loads in flight, then a fixed
-// shuffle/LDS tree (same order every run).
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int n_rows, int width,
-                                                          float* __restrict__ out) {
+// shuffle/LDS tree (same order every run).  Up to REDUCE_MAX_JOBS independent reductions share one launch (only
+// Adam reads the results, so the backward pass collects them and issues them once, off the dgrad chain).
+constexpr int REDUCE_MAX_JOBS = 4;
+struct ReduceJobs {
+    const float* part[REDUCE_MAX_JOBS];
+    float* out[REDUCE_MAX_JOBS];
+    int n_rows[REDUCE_MAX_JOBS], width[REDUCE_MAX_JOBS];
+    int block_start[REDUCE_MAX_JOBS + 1];  // first workgroup of each job
+    int n;
+};
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceJobs jobs) {
     __shared__ float s_red[32][8];
-    const int col = blockIdx.x * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;  // rl in [0, 32)
+    int job = 0;
+#pragma unroll
+    for (int i = 1; i < REDUCE_MAX_JOBS; ++i)
+        if (i < jobs.n && (int)blockIdx.x >= jobs.block_start[i]) job = i;
+    const float* __restrict__ part = jobs.part[job];
+    float* __restrict__ out = jobs.out[job];
+    const int n_rows = jobs.n_rows[job], width = jobs.width[job];
+    const int col = ((int)blockIdx.x - jobs.block_start[job]) * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;  // rl in [0, 32)
     float s = 0.f;
     if (col < width) {
         int r = rl;

@@ -1165,8 +1165,14 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
 
 // image-resident data gradient of conv layer `l` fused with the LayerNorm/ReLU backward of layer `below`:
 // writes dz of `below` and the reduced (dgamma, dbeta, dbias) row of `below`.  *done = false: not applicable.
+static void add_reduce_job(ReduceJobs& jobs, const float* part, int n_rows, int width, float* out) {
+    const int i = jobs.n++;
+    jobs.part[i] = part; jobs.out[i] = out; jobs.n_rows[i] = n_rows; jobs.width[i] = width;
+    jobs.block_start[i + 1] = jobs.block_start[i] + ceil_div(width, 8);
+}
+
 static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const float* params, const float* dz, float* ws,
-                          int n_img, hipStream_t st, bool* done) {
+                          int n_img, hipStream_t st, bool* done, ReduceJobs* jobs) {
     *done = false;
     if (!l.dgi_tiles || below.part_rows < n_img * l.dgi_tiles) return ISDQN_OK;
     ConvDgradImgParams dp;
@@ -1211,10 +1217,7 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
     if (passes == 3) rc = mt == 2 ? launch_conv_dgrad_img<2, 3>(dp, st) : launch_conv_dgrad_img<4, 3>(dp, st);
     else rc = mt == 2 ? launch_conv_dgrad_img<2, 1>(dp, st) : launch_conv_dgrad_img<4, 1>(dp, st);
     if (rc) return rc;
-    const int width = 3 * below.out_p;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(width, 8)), dim3(256), 0, st, ws + below.part_off,
-                       n_img * dp.tiles_per_img, width, ws + below.red_off);
-    ISDQN_HIP_CHECK(hipGetLastError());
+    add_reduce_job(*jobs, ws + below.part_off, n_img * dp.tiles_per_img, 3 * below.out_p, ws + below.red_off);
     *done = true;
     return ISDQN_OK;
 }
@@ -1475,6 +1478,9 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     const float* dz_cur = ws + P.dout_off;  // gradient w.r.t. the current layer's pre-activation output
     int dz_ld = P.nha_p;
     bool dz_fused = false;  // dz of layer i was already produced by the fused data gradient of layer i+1
+    ReduceJobs red_jobs;    // partial-row reductions left by the fused data gradients (one launch before Adam)
+    red_jobs.n = 0;
+    red_jobs.block_start[0] = 0;
     bool head_deferred = hc_S && ss;  // loss_finalize + head weight gradient still to be enqueued on the side stream
     auto run_head_deferred = [&](hipStream_t s2) -> int {
         if (!head_deferred) return ISDQN_OK;
@@ -1538,7 +1544,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         dz_fused = false;
         if (i > 0) {
             if (l.kind == 0) {
-                rc = conv_dgrad_img(l, P.L[i - 1], x3, params, dz_cur, ws, B, st, &dz_fused);
+                rc = conv_dgrad_img(l, P.L[i - 1], x3, params, dz_cur, ws, B, st, &dz_fused, &red_jobs);
                 if (rc) return rc;
             }
             if (l.kind == 1 && P.L[i - 1].kind == 0 && P.L[i - 1].cout_p == 64 && !l.in_unpadded_ld &&
@@ -1559,10 +1565,8 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 };
                 rc = x3 ? launch(DenseDgradLN<3>{}) : launch(DenseDgradLN<1>{});
                 if (rc) return rc;
-                const int width = 3 * below.out_p;
-                hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(width, 8)), dim3(256), 0, st, ws + below.part_off,
-                                   ceil_div(B, 128) * (l.in_p / 64), width, ws + below.red_off);
-                ISDQN_HIP_CHECK(hipGetLastError());
+                add_reduce_job(red_jobs, ws + below.part_off, ceil_div(B, 128) * (l.in_p / 64), 3 * below.out_p,
+                               ws + below.red_off);
                 dz_fused = true;
             }
             if (dz_fused || head_chained) {
@@ -1644,6 +1648,10 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     if (ss) {  // all weight gradients done before Adam (and before the next call touches the workspace)
         rc = chain(ss, wst, st);
         if (rc) return rc;
+    }
+    if (red_jobs.n > 0) {
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(red_jobs.block_start[red_jobs.n]), dim3(256), 0, st, red_jobs);
+        ISDQN_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, tab, params, adam_m, adam_v, ws + P.adam_tab_off,
                        cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps, grad_out);
