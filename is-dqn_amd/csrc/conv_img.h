@@ -738,6 +738,7 @@ struct ConvDgradImgParams {
     int n_img, T, Kc;    // taps per dim per class, K of a class = T*T*cout_p
     int Hd, Wd, PPd, bt; // padded dz image rows / cols, pixel pitch (elements), top/left border
     FastDiv d_chunk, d_Wd, d_T;  // fill index math (chunks per pixel, padded width) and taps per axis of a class
+    long long* stamps;           // profiling only (isdqn_debug_set_stamps), as in ConvImgParams
     int dz_plane;
     int tiles_per_img;   // sum over classes of ceil(class pixels / 128)
     int cls_tile_start[5];
@@ -761,6 +762,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     __shared__ float s_part[4][3][64];
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4;
+#define ISDQN_STAMP(i)                                                                               \
+    if (p.stamps != nullptr && threadIdx.x == 0) {                                                  \
+        p.stamps[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime();           \
+        if ((i) == 0) p.stamps[(int64_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    }
+    ISDQN_STAMP(0);
 
     const int j = (int)blockIdx.x / p.tiles_per_img;
     int tl = (int)blockIdx.x - j * p.tiles_per_img;
@@ -877,6 +884,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
         }
     }
 
+    ISDQN_STAMP(1);  // dz image staged (this wave)
     // ---- per-lane pixel of the two column tiles ----
     int b_org[NT], pix_iy[NT], pix_ix[NT];
     bool pix_ok[NT];
@@ -961,6 +969,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     fetch(0, slice(PF) * GEMM_BK);
     fetch(1, slice(PF + 1) * GEMM_BK);
     __syncthreads();
+    ISDQN_STAMP(2);
     read_frags(0, slice(0), fr[0]);
     for (int s0 = 0; s0 < nsteps_p; s0 += PF) {
 #pragma unroll
@@ -981,6 +990,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
         }
     }
 
+    ISDQN_STAMP(3);  // K loop done
     // ---- epilogue: LayerNorm + ReLU backward of the layer below, per input pixel (column) ----
     float ga[MT][4], be[MT][4];
 #pragma unroll
@@ -1072,12 +1082,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                dg[mt][r] += __shfl_xor(dg[mt][r], off);
-                db[mt][r] += __shfl_xor(db[mt][r], off);
-                dbias[mt][r] += __shfl_xor(dbias[mt][r], off);
-            }
+            dg[mt][r] = row16_sum(dg[mt][r]);
+            db[mt][r] = row16_sum(db[mt][r]);
+            dbias[mt][r] = row16_sum(dbias[mt][r]);
             if ((lane & 15) == 0) {
                 const int ch = mt * 16 + grp * 4 + r;
                 s_part[wave][0][ch] = dg[mt][r];
@@ -1091,6 +1098,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
         p.part[((int64_t)blockIdx.x * 3 + which) * g.cin_p + c] =
             s_part[0][which][c] + s_part[1][which][c] + s_part[2][which][c] + s_part[3][which][c];
     }
+    ISDQN_STAMP(4);  // epilogue stores issued
+    if (p.stamps != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0);
+        ISDQN_STAMP(5);
+    }
+#undef ISDQN_STAMP
 }
 
 // Deterministic reduction of per-workgroup partial rows: out[c] = sum_r part[r][c].  One workgroup per 8

@@ -19,6 +19,7 @@
 //   MFMA cost instead of 16/16;  2 = same with an operand B that is exact in bf16
 //   (uint8 pixels), so its lo plane is skipped.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace isdqn {
@@ -283,6 +284,21 @@ __device__ __forceinline__ void zero8(float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = 0.f;
 }
+// Sum over the 16 lanes of a DPP row (lanes 16q .. 16q+15), result in every lane of the row.  Four v_add_f32 with
+// DPP modifiers (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8) instead of four ds_bpermute round
+// trips through the LDS crossbar: the epilogues that reduce LayerNorm statistics and per-channel partial sums over
+// the 16 pixel lanes of an MFMA accumulator issue hundreds of these per wave.
+__device__ __forceinline__ float row16_sum(float x) {
+    auto dpp = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    x += dpp(x, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    x += dpp(x, std::integral_constant<int, 0x124>{});  // row_ror:4
+    x += dpp(x, std::integral_constant<int, 0x128>{});  // row_ror:8
+    return x;
+}
+
 // Loaders are BRANCH-FREE and MASK-FREE.  A load inside a divergent `if` makes hipcc branch around it and wait
 // for it (s_waitcnt at the join); a select on the loaded registers right after the load (v = ok ? v : 0) is no
 // better: it is a use of the data, so the compiler waits (vmcnt(0)) at the load site and a "prefetch" issued

@@ -834,7 +834,7 @@ __global__ void argmax_kernel(const float* __restrict__ q, int A, int head, int*
 // profiling hook (not in the public header): phase stamps of the image-resident forward kernel of one layer
 static long long* g_stamps = nullptr;
 static int g_stamp_layer = -1;
-static char g_stamp_name[16] = "";
+static char g_stamp_name[32] = "";
 extern "C" int isdqn_debug_set_stamps(void* buf, const char* layer_name) {
     g_stamps = (long long*)buf;
     g_stamp_layer = buf ? 0 : -1;
@@ -1198,6 +1198,7 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
     dp.d_chunk = FastDiv((uint32_t)(l.cout_p / 8));
     dp.d_Wd = FastDiv((uint32_t)dp.Wd);
     dp.d_T = FastDiv((uint32_t)dp.T);
+    dp.stamps = (g_stamp_layer >= 0 && strncmp(g_stamp_name, "dgrad:", 6) == 0 && strcmp(l.name, g_stamp_name + 6) == 0) ? g_stamps : nullptr;
     dp.n_classes = l.stride * l.stride;
     int acc = 0;
     for (int c = 0; c < dp.n_classes; ++c) {

@@ -236,6 +236,18 @@ struct DenseDgradLN {
             dg[nt] = db[nt] = dbias[nt] = 0.f;
         }
         const float inv_c = 1.f / (float)c_in;
+        // all pre-activations of this lane first (MT*4*NT independent loads in flight), then the arithmetic: loaded
+        // inside the row loop, each row would wait for its own round trip
+        float zall[MT][4][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m_wave + mt * 16 + grp * 4 + r;
+                const int64_t base = (int64_t)(row < M ? row : 0) * ldc + t.n0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) zall[mt][r][nt] = *(const ISDQN_GLOBAL float*)(z + base + nt * 16 + li);
+            }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -245,7 +257,7 @@ struct DenseDgradLN {
                 const int64_t base = (int64_t)(row_ok ? row : 0) * ldc + t.n0;
                 float zv[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) zv[nt] = z[base + nt * 16 + li];
+                for (int nt = 0; nt < NT; ++nt) zv[nt] = zall[mt][r][nt];
                 float out[NT];
                 if (gamma != nullptr) {
                     float s1 = 0.f, s2 = 0.f;
@@ -255,8 +267,8 @@ struct DenseDgradLN {
                         s1 += ok ? zv[nt] : 0.f;
                         s2 += ok ? zv[nt] * zv[nt] : 0.f;
                     }
-#pragma unroll
-                    for (int off = 1; off < 16; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+                    s1 = row16_sum(s1);
+                    s2 = row16_sum(s2);
                     const float mean = s1 * inv_c;
                     const float rstd = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + 1e-6f);
                     float xh[NT], gg[NT], m1 = 0.f, m2 = 0.f;
@@ -272,8 +284,8 @@ struct DenseDgradLN {
                         m1 += gg[nt];
                         m2 += gg[nt] * xh[nt];
                     }
-#pragma unroll
-                    for (int off = 1; off < 16; off <<= 1) { m1 += __shfl_xor(m1, off); m2 += __shfl_xor(m2, off); }
+                    m1 = row16_sum(m1);
+                    m2 = row16_sum(m2);
                     m1 *= inv_c;
                     m2 *= inv_c;
 #pragma unroll

@@ -38,6 +38,7 @@ span_cyc = s[:, 5].max() - t0
 span_rt = (s[:, 7].max() - s[:, 7].min())  # start-to-last-start only; use as lower bound
 order = np.argsort(s[:, 0])
 names = ["fill(load+convert+write)", "weights0+sync", "K loop", "epilogue issue", "store drain"]
+print("(layer may be e.g. Conv_1 for the forward kernel or dgrad:Conv_1 for the data-gradient kernel of that layer)")
 d = np.diff(s[:, :6], axis=1)
 ghz = float(os.environ.get("GHZ", "2.0"))
 print("start spread (cyc): p50 %.0f  p99 %.0f  max %.0f" % tuple(np.percentile(s[:, 0] - t0, [50, 99, 100])))
