@@ -1549,7 +1549,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 if (rc) return rc;
             }
             if (l.kind == 1 && P.L[i - 1].kind == 0 && P.L[i - 1].cout_p == 64 && !l.in_unpadded_ld &&
-                P.L[i - 1].part_rows >= ceil_div(B, 128) * P.L[i - 1].npix) {
+                P.L[i - 1].part_rows >= ceil_div(B, 64) * P.L[i - 1].npix) {
                 // first dense layer over a 64-channel conv output: data gradient + LN/ReLU backward in one kernel
                 const Layer& below = P.L[i - 1];
                 auto launch = [&](auto prob) {
@@ -1561,12 +1561,12 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                     prob.dz_out = ws + below.dz_off;
                     prob.part = ws + below.part_off;
                     prob.ldc = l.in_p; prob.M = B; prob.N = l.in_p; prob.K = l.out_p; prob.c_in = below.out_f;
-                    prob.tiles_m = ceil_div(B, 128); prob.tiles_n = l.in_p / 64;
+                    prob.tiles_m = ceil_div(B, decltype(prob)::BM); prob.tiles_n = l.in_p / 64;
                     return launch_gemm(prob, prob.tiles_m * prob.tiles_n, st);
                 };
                 rc = x3 ? launch(DenseDgradLN<3>{}) : launch(DenseDgradLN<1>{});
                 if (rc) return rc;
-                add_reduce_job(red_jobs, ws + below.part_off, ceil_div(B, 128) * (l.in_p / 64), 3 * below.out_p,
+                add_reduce_job(red_jobs, ws + below.part_off, ceil_div(B, 64) * (l.in_p / 64), 3 * below.out_p,
                                ws + below.red_off);
                 dz_fused = true;
             }

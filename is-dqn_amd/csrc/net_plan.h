@@ -256,9 +256,9 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
         if (i + 1 < nl && P.L[i + 1].dgi_tiles > 0 && P.B * P.L[i + 1].dgi_tiles > l.part_rows)
             l.part_rows = P.B * P.L[i + 1].dgi_tiles;
         // conv layer under the first dense layer: the fused dense data-gradient + LN backward emits one partial
-        // row per (128-sample tile, pixel)
-        if (l.kind == 0 && i + 1 < nl && P.L[i + 1].kind == 1 && l.cout_p == 64 && ceil_div(P.B, 128) * l.npix > l.part_rows)
-            l.part_rows = ceil_div(P.B, 128) * l.npix;
+        // row per (64-sample tile, pixel)
+        if (l.kind == 0 && i + 1 < nl && P.L[i + 1].kind == 1 && l.cout_p == 64 && ceil_div(P.B, 64) * l.npix > l.part_rows)
+            l.part_rows = ceil_div(P.B, 64) * l.npix;
         l.part_off = region(std::string("part/") + l.name, (int64_t)l.part_rows * 3 * l.out_p);
     }
     P.q_off = region("q", (int64_t)P.N2 * P.nha_p);

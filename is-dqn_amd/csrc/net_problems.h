@@ -195,9 +195,10 @@ struct PlainGemm {
 // reads z of the conv output, writes dz of the conv layer directly (da never goes to HBM) and emits the
 // workgroup's partial sums of (dgamma, dbeta, dbias).
 // ---------------------------------------------------------------------------------------------
-template <int PASSES_>
+// BM_: 128 or 64 rows per workgroup (64 doubles the workgroup count: the 3136-column problem has only 49 column tiles)
+template <int PASSES_, int BM_ = 64>
 struct DenseDgradLN {
-    static constexpr int BM = 128, BN = 64, WM = 4, WN = 1, PASSES = PASSES_;
+    static constexpr int BM = BM_, BN = 64, WM = 4, WN = 1, PASSES = PASSES_;
     static constexpr bool A_TR = false, B_TR = true;
     static constexpr int EPI_LDS_BYTES = 4 * 3 * 64 * 4;
     MatSrc A, B;
