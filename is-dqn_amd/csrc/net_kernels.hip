@@ -1626,10 +1626,12 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 AdamFuse af{params + l.w_off, adam_m + l.w_off, adam_v + l.w_off, ws + P.adam_tab_off,
                             cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps,
                             grad_out ? grad_out + l.w_off : nullptr};
-                rc = x3 ? launch_plain<128, 128, 2, 2, true, true, 3, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                         l.out_p, l.in_p, B, 1, 0, lws, &af)
-                        : launch_plain<128, 128, 2, 2, true, true, 1, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                         l.out_p, l.in_p, B, 1, 0, lws, &af);
+                // 64x64 tiles: the contraction is only B deep, the kernel lives off streaming p/m/v through the Adam
+                // epilogue, and 128x128 tiles would leave 100 workgroups for 256 CUs
+                rc = x3 ? launch_plain<64, 64, 2, 2, true, true, 3, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                       l.out_p, l.in_p, B, 1, 0, lws, &af)
+                        : launch_plain<64, 64, 2, 2, true, true, 1, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                       l.out_p, l.in_p, B, 1, 0, lws, &af);
             } else {
                 rc = l.in_unpadded_ld
                          ? plain_big<true, true, false>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
