@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) mfma_init(acc[mt][nt]);
 
 
     // Fragments of one K step: MTW weight tiles and NT pixel tiles, each hi (+ lo).  Two sets alternate so that the
@@ -284,10 +284,10 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 if constexpr (PASSES >= 3)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_hi[mt], f.b_lo[nt], acc[mt][nt], 0, 0, 0);
+                    mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_lo[nt]);
                 if constexpr (PASSES >= 2)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_lo[mt], f.b_hi[nt], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_hi[mt], f.b_hi[nt], acc[mt][nt], 0, 0, 0);
+                    mfma_acc(acc[mt][nt], f.a_lo[mt], f.b_hi[nt]);
+                mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_hi[nt]);
             }
     };
 
@@ -315,12 +315,14 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
         // (fragments read during step s-1), the conversion of slice s+2 into stage s&1 (whose readers finished before
         // the last barrier) and the request for slice s+2+PF.
         read_frags(0, slice(0), fr[0]);
+        __syncthreads();  // every wave has read stage 0 before step 0 overwrites it with slice 2
         for (int s0 = 0; s0 < nsteps_p; s0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int s = s0 + u;
                 read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
                 mfma_step(fr[u & 1]);
+                mfma_drain(s + 1 >= nsteps_p);
                 stash((u + 2) % PF, s & 1);
                 fetch((u + 2) % PF, slice(s + 2 + PF) * GEMM_BK);
                 // Issue order for the block: a 16x16x32 MFMA occupies the matrix pipe for 16 cycles but the issue port
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const Conv
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTW; ++t) mfma_init(acc[mt][t]);
 
     const int nsteps = p.npix_pad / GEMM_BK;
     for (int j = j0; j < j1; ++j) {
@@ -673,12 +675,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const Conv
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if constexpr (PASSES >= 3)
-                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_lo, acc[mt][t], 0, 0, 0);
+                        mfma_acc(acc[mt][t], fa_hi[mt], fb_lo);
                     if constexpr (PASSES >= 2)
-                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[mt], fb_hi, acc[mt][t], 0, 0, 0);
-                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_hi, acc[mt][t], 0, 0, 0);
+                        mfma_acc(acc[mt][t], fa_lo[mt], fb_hi);
+                    mfma_acc(acc[mt][t], fa_hi[mt], fb_hi);
                 }
             }
+            mfma_drain(ks + 1 == nsteps && j + 1 == j1);
         }
     }
 
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) mfma_init(acc[mt][nt]);
 
     struct Frags {
         bf16x8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
@@ -939,10 +942,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (PASSES >= 3)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_hi[mt], f.b_lo[nt], acc[mt][nt], 0, 0, 0);
+                    mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_lo[nt]);
                 if constexpr (PASSES >= 2)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_lo[mt], f.b_hi[nt], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a_hi[mt], f.b_hi[nt], acc[mt][nt], 0, 0, 0);
+                    mfma_acc(acc[mt][nt], f.a_lo[mt], f.b_hi[nt]);
+                mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_hi[nt]);
             }
     };
 
@@ -971,12 +974,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     __syncthreads();
     ISDQN_STAMP(2);
     read_frags(0, slice(0), fr[0]);
+    __syncthreads();  // every wave has read stage 0 before step 0 overwrites it with slice 2
     for (int s0 = 0; s0 < nsteps_p; s0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int s = s0 + u;
             read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
             mfma_step(fr[u & 1]);
+            mfma_drain(s + 1 >= nsteps_p);
             stash((u + 2) % PF, s & 1);
             fetch((u + 2) % PF, slice(s + 2 + PF) * GEMM_BK);
             constexpr int N_MFMA = MT * NT * (PASSES >= 3 ? 3 : PASSES);

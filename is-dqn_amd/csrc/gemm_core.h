@@ -65,6 +65,45 @@ struct TileGeom {
     static constexpr int PER_THREAD = (CHUNKS + GEMM_THREADS - 1) / GEMM_THREADS;
 };
 
+// acc += A * B on the matrix pipe, IN PLACE.  The MFMA is issued through inline asm with the accumulator as a tied
+// read-write operand, so vDst == SrcC always.  With the builtin, hipcc (ROCm 7.2) renames accumulators when few are
+// live (the four-accumulator MT = 2 kernels, and the pipelined 8-accumulator loops), emitting e.g.
+//     v_mfma a[4:7],  A_lo, B, a[4:7]
+//     (four v_accvgpr_read)
+//     v_mfma a[8:11], A_hi, B, a[4:7]      <- SrcC = result of the MFMA a few instructions earlier, other vDst
+//     v_accvgpr_write a4..a7, ...          <- over registers that MFMA may still be writing
+// In-place chains are interlocked by the hardware; this renamed form relies on compiler-inserted wait states, and on
+// gfx950 they were not enough: about 1 % of workgroups (more when waves share a SIMD) produced a tile that lacked one
+// MFMA pass.  Found by the full-size run-to-run determinism test (tests/test_gpu_fullsize_properties.py).
+// Consequences of the asm: the compiler no longer knows these are MFMAs, so (1) the wait before the accumulators are
+// read is ours -- mfma_drain() below, INSIDE the loop's last iteration -- and (2) operands written by VALU need a few
+// wait states in front of the MFMA (only the head chain converts operands in registers; everywhere else they come
+// from ds_reads, whose s_waitcnt the compiler still inserts because it tracks the asm's register operands).
+// (3) the same holds between the zero-initialisation of an accumulator (v_accvgpr_write) and the first MFMA that
+// reads it: mfma_init() pads behind the initialisation.
+__device__ __forceinline__ void mfma_init(f32x4& acc) {
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_nop 1" : "+a"(acc));
+}
+__device__ __forceinline__ void mfma_acc(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+// Wait states between the last MFMA of a K loop and the first read of its accumulators.  hipcc (ROCm 7.2) copies the
+// accumulators out of the AGPRs (v_accvgpr_read) in the loop's EXIT block, i.e. directly behind the final
+// v_mfma_f32_16x16x32_bf16 of the loop body and the closing barrier, with whatever s_nops its hazard table asks for.
+// On gfx950 that was not enough: in roughly 1 % of workgroups -- more often the more waves share a SIMD -- a tile came
+// back without its last MFMA contribution.  Found by the full-size run-to-run determinism test
+// (tests/test_gpu_fullsize_properties.py) and bisected to exactly this (the same kernel with an epilogue that first
+// waits on global loads was bit-stable; padding placed after the loop lands BEHIND the compiler's copies and does
+// nothing).  So the padding goes INSIDE the loop body, behind the MFMAs of the last iteration: 32 cycles cover an
+// 8-pass MFMA that had to queue behind another wave's.  `last` must be wave-uniform.
+__device__ __forceinline__ void mfma_drain(bool last = true) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (last) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // Fragment of 16 rows x 32 k for lane `lane`: element j <-> (row = row0 + (lane&15), k = 8*(lane>>4) + j).
 template <bool TR, int PITCH>
 __device__ __forceinline__ bf16x8 read_frag(const __bf16* tile, int row0, int lane) {
@@ -214,7 +253,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) mfma_init(acc[mt][nt]);
 
     auto compute = [&](int stage) {
         const __bf16* base = smem + stage * T::STAGE_ELEMS;
@@ -236,10 +275,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (PASSES >= 3)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_lo, acc[mt][nt], 0, 0, 0);
+                    mfma_acc(acc[mt][nt], fa_hi[mt], fb_lo);
                 if constexpr (PASSES >= 2)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_lo[mt], fb_hi, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_hi[mt], fb_hi, acc[mt][nt], 0, 0, 0);
+                    mfma_acc(acc[mt][nt], fa_lo[mt], fb_hi);
+                mfma_acc(acc[mt][nt], fa_hi[mt], fb_hi);
             }
         }
     };
@@ -254,6 +293,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
             const bool more = s + 1 < nsteps;
             if (more) fetch(tile.k0 + (s + 1) * GEMM_BK);
             compute(s & 1);
+            mfma_drain(!more);
             if (more) stash((s + 1) & 1);
             __syncthreads();
         }

@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
         const int arow = (lane & 15) * PA + kg8;
         for (int nt = 0; nt < NT; nt += 2) {
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            asm volatile("s_nop 7" : "+a"(acc[0]), "+a"(acc[1]));  // accumulator init (VALU) -> asm MFMA: no compiler padding
             for (int ksb = wave; ksb < nkt; ksb += 16) {
                 float v[2][4][8];
 #pragma unroll
@@ -474,15 +475,20 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
                         bf16x8 bh, bl;
                         if constexpr (PASSES >= 2) {
                             split8(v[t][u], bh, bl);
+                            // VALU-written operands -> asm MFMA: no compiler hazard handling, and the pad must be tied
+                            // to the operands or the scheduler sinks the conversions below it
+                            asm volatile("s_nop 4" : "+v"(bh), "+v"(bl));
                             if constexpr (PASSES >= 3)
-                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[t], 0, 0, 0);
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[t], 0, 0, 0);
+                                mfma_acc(acc[t], ah, bl);
+                            mfma_acc(acc[t], al, bh);
                         } else {
                             round8(v[t][u], bh);
+                            asm volatile("s_nop 4" : "+v"(bh));
                         }
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[t], 0, 0, 0);
+                        mfma_acc(acc[t], ah, bh);
                     }
                 }
+                mfma_drain(ksb + 16 >= nkt);
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {

@@ -19,6 +19,13 @@ CONFIGS = [
     pytest.param(((7, 9, 11, 13), 3, 5, 6, True), id="tiny-ln"),
     pytest.param(((16, 20, 5, 24), 2, 3, 5, False), id="tiny-noln"),
     pytest.param(((32, 64, 64, 512), 9, 9, 8, True), id="headline-arch-B8"),
+    # ragged edges of the fused kernels: B not a multiple of the head chain's 4 transitions per workgroup
+    pytest.param(((32, 64, 64, 512), 9, 9, 7, True), id="headline-arch-B7-ragged"),
+    # configs[4] head shape (K=32, A=4: 132 outputs -> 9 column tiles, padded to 136)
+    pytest.param(((32, 64, 64, 512), 32, 4, 12, True), id="c5-head-B12"),
+    # 18 actions (full Atari set), B crossing no 64-row tile boundary evenly
+    pytest.param(((32, 64, 64, 512), 4, 18, 33, True), id="a18-B33"),
+    pytest.param(((32, 64, 64, 512), 3, 6, 10, False), id="headline-arch-noln"),
 ]
 
 
