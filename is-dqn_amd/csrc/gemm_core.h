@@ -86,7 +86,7 @@ __device__ __forceinline__ void mfma_init(f32x4& acc) {
     asm volatile("s_nop 1" : "+a"(acc));
 }
 __device__ __forceinline__ void mfma_acc(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
 // Wait states between the last MFMA of a K loop and the first read of its accumulators.  hipcc (ROCm 7.2) copies the
