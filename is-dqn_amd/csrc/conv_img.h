@@ -52,30 +52,29 @@ struct ConvImgTraits {
     static constexpr int A_STAGE = A_PLANES * GA::ELEMS;
 };
 
-// NW = 4: each wave owns all MT channel tiles of 32 pixels.  NW = 8: two waves per SIMD share the LDS image; wave
-// (mh, pw) owns channel half mh of pixel group pw, and the LayerNorm statistics of a pixel are exchanged through LDS.
-template <int MT, int PASSES, bool U8, int NW>
-__global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgParams p) {
+// Four waves; each owns all MT channel tiles of 32 output pixels.  (An eight-wave variant -- two waves per SIMD sharing
+// the image, channel halves per wave -- was measured slower: barrier-locked waves do not overlap each other.)
+template <int MT, int PASSES, bool U8>
+__global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvImgParams p) {
     using T = ConvImgTraits<MT, PASSES, U8>;
     using GA = typename T::GA;
     constexpr int NT = 2;
-    constexpr int NTHR = NW * 64;
-    constexpr int MTW = NW == 8 ? MT / 2 : MT;  // channel tiles per wave
-    static_assert(NW == 4 || (NW == 8 && MT % 2 == 0), "wave layout");
+    constexpr int NTHR = GEMM_THREADS;
+    constexpr int MTW = MT;  // channel tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* a_stage = smem;                              // 2 stages of weight K-slices
     __bf16* img = smem + 2 * T::A_STAGE;                 // B_PLANES planes of the input tile
     const ConvGeom& g = p.g;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, mh = tid >> 8;  // mh = 0 when NW == 4
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define ISDQN_STAMP(i)                                                                               \
     if (p.stamps != nullptr && threadIdx.x == 0) {                                                  \
         p.stamps[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime();           \
         if ((i) == 0) p.stamps[(int64_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memrealtime(); \
     }
     ISDQN_STAMP(0);
-    const int mt0 = mh * MTW;
+    constexpr int mt0 = 0;
     const int j = (int)blockIdx.x / p.tiles_per_img;
     const int tile = (int)blockIdx.x - j * p.tiles_per_img;
     const int p0 = tile * 128;
@@ -377,26 +376,6 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
             s2[nt] += __shfl_xor(s2[nt], 16); s2[nt] += __shfl_xor(s2[nt], 32);
         }
     }
-    if constexpr (NW == 8) {
-        if (p.gamma != nullptr) {  // the other channel half of each pixel lives in wave (1 - mh, pw): swap partial sums
-            float* st = reinterpret_cast<float*>(smem);  // weight stages are dead after the K loop's last barrier
-            if (grp == 0) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int px = wave * 32 + nt * 16 + (lane & 15);
-                    st[(mh * 128 + px) * 2] = s1[nt];
-                    st[(mh * 128 + px) * 2 + 1] = s2[nt];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int px = wave * 32 + nt * 16 + (lane & 15);
-                s1[nt] += st[((1 - mh) * 128 + px) * 2];
-                s2[nt] += st[((1 - mh) * 128 + px) * 2 + 1];
-            }
-        }
-    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int pp = p0 + wave * 32 + nt * 16 + (lane & 15);
@@ -434,17 +413,17 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_img_kernel(const ConvImgPara
 #undef ISDQN_STAMP
 }
 
-template <int MT, int PASSES, bool U8, int NW>
+template <int MT, int PASSES, bool U8>
 static int launch_conv_fwd_img(const ConvImgParams& p, hipStream_t st) {
     using T = ConvImgTraits<MT, PASSES, U8>;
     const int lds = (2 * T::A_STAGE + T::B_PLANES * p.plane_elems) * 2;
     static int configured_for = 0;
     if (lds > 65536 && lds > configured_for) {
-        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_img_kernel<MT, PASSES, U8, NW>),
+        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_img_kernel<MT, PASSES, U8>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured_for = lds;
     }
-    hipLaunchKernelGGL((conv_fwd_img_kernel<MT, PASSES, U8, NW>), dim3(p.n_img * p.tiles_per_img), dim3(NW * 64), lds,
+    hipLaunchKernelGGL((conv_fwd_img_kernel<MT, PASSES, U8>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS), lds,
                        st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;

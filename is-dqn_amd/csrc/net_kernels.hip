@@ -914,21 +914,11 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     }
     *done = true;
     if (l.is_u8) {
-        static const int nw_u8 = getenv("ISDQN_FWD_NW_U8") ? atoi(getenv("ISDQN_FWD_NW_U8")) : 4;
-        if (nw_u8 == 8) {
-            if (passes == 2) return mt == 2 ? launch_conv_fwd_img<2, 2, true, 8>(ip, st) : launch_conv_fwd_img<4, 2, true, 8>(ip, st);
-            return mt == 2 ? launch_conv_fwd_img<2, 1, true, 8>(ip, st) : launch_conv_fwd_img<4, 1, true, 8>(ip, st);
-        }
-        if (passes == 2) return mt == 2 ? launch_conv_fwd_img<2, 2, true, 4>(ip, st) : launch_conv_fwd_img<4, 2, true, 4>(ip, st);
-        return mt == 2 ? launch_conv_fwd_img<2, 1, true, 4>(ip, st) : launch_conv_fwd_img<4, 1, true, 4>(ip, st);
+        if (passes == 2) return mt == 2 ? launch_conv_fwd_img<2, 2, true>(ip, st) : launch_conv_fwd_img<4, 2, true>(ip, st);
+        return mt == 2 ? launch_conv_fwd_img<2, 1, true>(ip, st) : launch_conv_fwd_img<4, 1, true>(ip, st);
     }
-    static const int nw = getenv("ISDQN_FWD_NW") ? atoi(getenv("ISDQN_FWD_NW")) : 4;
-    if (nw == 8) {
-        if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false, 8>(ip, st) : launch_conv_fwd_img<4, 3, false, 8>(ip, st);
-        return mt == 2 ? launch_conv_fwd_img<2, 1, false, 8>(ip, st) : launch_conv_fwd_img<4, 1, false, 8>(ip, st);
-    }
-    if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false, 4>(ip, st) : launch_conv_fwd_img<4, 3, false, 4>(ip, st);
-    return mt == 2 ? launch_conv_fwd_img<2, 1, false, 4>(ip, st) : launch_conv_fwd_img<4, 1, false, 4>(ip, st);
+    if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false>(ip, st) : launch_conv_fwd_img<4, 3, false>(ip, st);
+    return mt == 2 ? launch_conv_fwd_img<2, 1, false>(ip, st) : launch_conv_fwd_img<4, 1, false>(ip, st);
 }
 
 static int conv_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int n_img,

@@ -223,7 +223,6 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
                     int ncg = l.K / (64 * ntw);
                     int G = (P.B * ncg + 255) / 256;
                     if (wide) G = (P.B + 127) / 128;  // ~128 workgroups of two images: measured best (1: 2681, 2: 2806 steps/s)
-                    if (const char* e = getenv("ISDQN_WGI_G")) G = atoi(e);
                     if (G < 1) G = 1;
                     l.wgi_ntw = ntw;
                     l.wgi_G = G;
