@@ -887,7 +887,10 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     *done = false;
     ConvImgParams ip;
     ip.g = conv_geom(l);
-    const int mt = l.cout_p <= 32 ? 2 : 4;
+    // always the four-channel-tile instantiation (8 accumulators per wave): with two tiles the kernel has four
+    // accumulators and returned a wrong tile about once per ten steps under sustained load;
+    // channels past cout_p are zero rows of the weight stage
+    const int mt = 4;
     const int passes = x3 ? (l.is_u8 ? 2 : 3) : 1;
     // pixel pitch: +8 / +16 elements so that the 16 pixels of an MFMA column tile do not share LDS banks
     // (128-byte pixel rows put them 4-5 deep on the same banks; measured model in DESIGN.md)
@@ -1545,7 +1548,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 if (rc) return rc;
             }
             if (l.kind == 1 && P.L[i - 1].kind == 0 && P.L[i - 1].cout_p == 64 && !l.in_unpadded_ld &&
-                P.L[i - 1].part_rows >= ceil_div(B, 64) * P.L[i - 1].npix) {
+                P.L[i - 1].part_rows >= ceil_div(B, 128) * P.L[i - 1].npix) {
                 // first dense layer over a 64-channel conv output: data gradient + LN/ReLU backward in one kernel
                 const Layer& below = P.L[i - 1];
                 auto launch = [&](auto prob) {
@@ -1560,9 +1563,11 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                     prob.tiles_m = ceil_div(B, decltype(prob)::BM); prob.tiles_n = l.in_p / 64;
                     return launch_gemm(prob, prob.tiles_m * prob.tiles_n, st);
                 };
-                rc = x3 ? launch(DenseDgradLN<3>{}) : launch(DenseDgradLN<1>{});
+                // 128-row tiles (8 accumulators per wave).  64-row tiles fill the chip better (196 workgroups, -3 us)
+                // but are a four-accumulator kernel, and those are not run-to-run stable on gfx950
+                rc = x3 ? launch(DenseDgradLN<3, 128>{}) : launch(DenseDgradLN<1, 128>{});
                 if (rc) return rc;
-                add_reduce_job(red_jobs, ws + below.part_off, ceil_div(B, 64) * (l.in_p / 64), 3 * below.out_p,
+                add_reduce_job(red_jobs, ws + below.part_off, ceil_div(B, 128) * (l.in_p / 64), 3 * below.out_p,
                                ws + below.red_off);
                 dz_fused = true;
             }

@@ -196,7 +196,7 @@ struct PlainGemm {
 // workgroup's partial sums of (dgamma, dbeta, dbias).
 // ---------------------------------------------------------------------------------------------
 // BM_: 128 or 64 rows per workgroup (64 doubles the workgroup count: the 3136-column problem has only 49 column tiles)
-template <int PASSES_, int BM_ = 64>
+template <int PASSES_, int BM_ = 128>
 struct DenseDgradLN {
     static constexpr int BM = BM_, BN = 64, WM = 4, WN = 1, PASSES = PASSES_;
     static constexpr bool A_TR = false, B_TR = true;
