@@ -229,11 +229,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
         b_org[nt] = U8 ? (ly0 * p.Wp + lx0) : (ly0 * p.Wp + lx0) * p.PP;
     }
 
-    f32x4 acc[MTW][NT];
+    // With two channel tiles a wave has only four accumulators, and four-accumulator kernels are not run-to-run stable
+    // on gfx950: the K steps then alternate between two accumulator sets (even / odd steps),
+    // eight live accumulators and no extra MFMA, added up once in front of the epilogue.
+    constexpr int NACC = (MTW * NT <= 4) ? 2 : 1;
+    f32x4 accs[NACC][MTW][NT];
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) mfma_init(acc[mt][nt]);
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mfma_init(accs[a][mt][nt]);
 
 
     // Fragments of one K step: MTW weight tiles and NT pixel tiles, each hi (+ lo).  Two sets alternate so that the
@@ -277,16 +283,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
             }
         }
     };
-    auto mfma_step = [&](const Frags& f) {
+    auto mfma_step = [&](const Frags& f, int step_parity) {  // (folds to a constant once the step loop is unrolled)
+        const int a = NACC == 2 ? step_parity : 0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 if constexpr (PASSES >= 3)
-                    mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_lo[nt]);
+                    mfma_acc(accs[a][mt][nt], f.a_hi[mt], f.b_lo[nt]);
                 if constexpr (PASSES >= 2)
-                    mfma_acc(acc[mt][nt], f.a_lo[mt], f.b_hi[nt]);
-                mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_hi[nt]);
+                    mfma_acc(accs[a][mt][nt], f.a_lo[mt], f.b_hi[nt]);
+                mfma_acc(accs[a][mt][nt], f.a_hi[mt], f.b_hi[nt]);
             }
     };
 
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
             for (int u = 0; u < PF; ++u) {
                 const int s = s0 + u;
                 read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
-                mfma_step(fr[u & 1]);
+                mfma_step(fr[u & 1], u & 1);
                 mfma_drain(s + 1 >= nsteps_p);
                 stash((u + 2) % PF, s & 1);
                 fetch((u + 2) % PF, slice(s + 2 + PF) * GEMM_BK);
@@ -339,6 +346,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
         }
     }
     ISDQN_STAMP(3);  // K loop done
+    f32x4 acc[MTW][NT];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = accs[0][mt][nt];
+            if constexpr (NACC == 2) acc[mt][nt] += accs[1][mt][nt];
+        }
     if (p.ablate & 4) {
         if (acc[0][0][0] == 12345.678f) p.act[0] = 1.f;  // keep the accumulators alive
         return;
@@ -883,11 +898,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
         b_org[nt] = ((oyb + p.bt) * p.Wd + oxb + p.bt) * p.PPd;
     }
 
-    f32x4 acc[MT][NT];
+    // two accumulator sets (even / odd K steps) when a wave would otherwise have only four accumulators: see
+    // conv_fwd_img_kernel
+    constexpr int NACC = (MT * NT <= 4) ? 2 : 1;
+    f32x4 accs[NACC][MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) mfma_init(acc[mt][nt]);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mfma_init(accs[a][mt][nt]);
 
     struct Frags {
         bf16x8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
@@ -915,16 +935,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
             if constexpr (PASSES >= 3) f.b_lo[nt] = *reinterpret_cast<const bf16x8*>(src + p.dz_plane);
         }
     };
-    auto mfma_step = [&](const Frags& f) {
+    auto mfma_step = [&](const Frags& f, int step_parity) {
+        const int a = NACC == 2 ? step_parity : 0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (PASSES >= 3)
-                    mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_lo[nt]);
+                    mfma_acc(accs[a][mt][nt], f.a_hi[mt], f.b_lo[nt]);
                 if constexpr (PASSES >= 2)
-                    mfma_acc(acc[mt][nt], f.a_lo[mt], f.b_hi[nt]);
-                mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_hi[nt]);
+                    mfma_acc(accs[a][mt][nt], f.a_lo[mt], f.b_hi[nt]);
+                mfma_acc(accs[a][mt][nt], f.a_hi[mt], f.b_hi[nt]);
             }
     };
 
@@ -959,7 +980,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
         for (int u = 0; u < PF; ++u) {
             const int s = s0 + u;
             read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
-            mfma_step(fr[u & 1]);
+            mfma_step(fr[u & 1], u & 1);
             mfma_drain(s + 1 >= nsteps_p);
             stash((u + 2) % PF, s & 1);
             fetch((u + 2) % PF, slice(s + 2 + PF) * GEMM_BK);
@@ -975,6 +996,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     }
 
     ISDQN_STAMP(3);  // K loop done
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = accs[0][mt][nt];
+            if constexpr (NACC == 2) acc[mt][nt] += accs[1][mt][nt];
+        }
     // ---- epilogue: LayerNorm + ReLU backward of the layer below, per input pixel (column) ----
     float ga[MT][4], be[MT][4];
 #pragma unroll

@@ -887,10 +887,8 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     *done = false;
     ConvImgParams ip;
     ip.g = conv_geom(l);
-    // always the four-channel-tile instantiation (8 accumulators per wave): with two tiles the kernel has four
-    // accumulators and returned a wrong tile about once per ten steps under sustained load;
-    // channels past cout_p are zero rows of the weight stage
-    const int mt = 4;
+    // (two channel tiles: the kernel then alternates two accumulator sets, see conv_fwd_img_kernel)
+    const int mt = (l.cout_p <= 32 && !getenv("ISDQN_FORCE_MT4")) ? 2 : 4;
     const int passes = x3 ? (l.is_u8 ? 2 : 3) : 1;
     // pixel pitch: +8 / +16 elements so that the 16 pixels of an MFMA column tile do not share LDS banks
     // (128-byte pixel rows put them 4-5 deep on the same banks; measured model in DESIGN.md)
