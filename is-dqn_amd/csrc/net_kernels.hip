@@ -27,24 +27,32 @@ __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict
     __shared__ float s_red[2][4];
     const int row = blockIdx.x, tid = threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
-    for (int c = tid; c < Fp; c += 256) {
-        float v = 0.f;
-        if (c < F) {
-            const float* p = slabs + (int64_t)row * Fp + c;
-            int s = 0;
-            for (; s + 8 <= n_slabs; s += 8) {  // 8 independent loads in flight, fixed summation order
-                float t[8];
+    // two adjacent columns per thread (Fp is a multiple of 8: 8-byte loads), 16 slabs in flight, fixed summation order
+    for (int c = 2 * tid; c < Fp; c += 512) {
+        float v0 = 0.f, v1 = 0.f;
+        const float* p = slabs + (int64_t)row * Fp + c;
+        int s = 0;
+        for (; s + 16 <= n_slabs; s += 16) {
+            float2 t[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = p[(int64_t)(s + u) * slab_stride];
+            for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const float2*>(p + (int64_t)(s + u) * slab_stride);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v += t[u];
-            }
-            for (; s < n_slabs; ++s) v += p[(int64_t)s * slab_stride];
-            v += bias[c];
+            for (int u = 0; u < 16; ++u) { v0 += t[u].x; v1 += t[u].y; }
         }
-        s_row[c] = v;
-        s1 += v;
-        s2 += v * v;
+        if (s < n_slabs) {
+            float2 t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)  // tail: clamped to the last slab, masked in the sum
+                t[u] = *reinterpret_cast<const float2*>(p + (int64_t)min(s + u, n_slabs - 1) * slab_stride);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { v0 += (s + u < n_slabs) ? t[u].x : 0.f; v1 += (s + u < n_slabs) ? t[u].y : 0.f; }
+        }
+        v0 = c < F ? v0 + bias[c] : 0.f;
+        v1 = c + 1 < F ? v1 + bias[c + 1] : 0.f;
+        s_row[c] = v0;
+        s_row[c + 1] = v1;
+        s1 += v0 + v1;
+        s2 += v0 * v0 + v1 * v1;
     }
     float mean = 0.f, rstd = 1.f;
     if (gamma != nullptr) {
@@ -63,14 +71,18 @@ __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict
         float var = fmaxf(s2 / (float)F - mean * mean, 0.f);
         rstd = rsqrtf(var + 1e-6f);
     }
-    for (int c = tid; c < Fp; c += 256) {
-        float v = s_row[c];  // written by this same thread
-        float y = v;
-        if (gamma != nullptr && c < F) y = (v - mean) * (rstd * gamma[c]) + beta[c];
-        if (has_relu) y = fmaxf(y, 0.f);
-        if (c >= F) y = 0.f;
-        act[(int64_t)row * Fp + c] = y;
-        if (row < z_rows) z[(int64_t)row * Fp + c] = v;
+    for (int c0 = 2 * tid; c0 < Fp; c0 += 512) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = c0 + e;
+            float v = s_row[c];  // written by this same thread
+            float y = v;
+            if (gamma != nullptr && c < F) y = (v - mean) * (rstd * gamma[c]) + beta[c];
+            if (has_relu) y = fmaxf(y, 0.f);
+            if (c >= F) y = 0.f;
+            act[(int64_t)row * Fp + c] = y;
+            if (row < z_rows) z[(int64_t)row * Fp + c] = v;
+        }
     }
 }
 
