@@ -20,7 +20,7 @@ __global__ __launch_bounds__(TREE_SET_THREADS) void tree_set_kernel(double* __re
                                                                     const int* __restrict__ indices,
                                                                     const double* __restrict__ values, int n,
                                                                     double* max_prio, uint32_t* status) {
-    __shared__ int s_node[ISDQN_TREE_MAX_BATCH];
+    __shared__ __attribute__((aligned(16))) int s_node[ISDQN_TREE_MAX_BATCH];
     __shared__ double s_delta[ISDQN_TREE_MAX_BATCH];
     __shared__ int u_node[ISDQN_TREE_MAX_BATCH];
     __shared__ double u_delta[ISDQN_TREE_MAX_BATCH];
@@ -75,11 +75,35 @@ __global__ __launch_bounds__(TREE_SET_THREADS) void tree_set_kernel(double* __re
         s_first[i] = (unsigned char)first;
     }
     __syncthreads();
-    for (int i = t; i < n; i += TREE_SET_THREADS) {
-        if (!s_first[i]) continue;
-        int node = s_node[i];
+    // rank of a first occurrence = number of first occurrences with a smaller node.  Later occurrences get the key
+    // INT_MAX so that one array and a branch-free compare suffice: with `s_first[j] && s_node[j] < node` the loop is a
+    // branch per element and its LDS reads cannot be pipelined (26 of the kernel's 44 us at n = 256).
+    int my_node[ISDQN_TREE_MAX_BATCH / TREE_SET_THREADS];
+#pragma unroll
+    for (int k = 0; k < ISDQN_TREE_MAX_BATCH / TREE_SET_THREADS; ++k) {
+        const int i = t + k * TREE_SET_THREADS;
+        my_node[k] = i < n ? s_node[i] : 0;
+    }
+    __syncthreads();  // everybody has its node in a register before the keys overwrite s_node
+#pragma unroll
+    for (int k = 0; k < ISDQN_TREE_MAX_BATCH / TREE_SET_THREADS; ++k) {
+        const int i = t + k * TREE_SET_THREADS;
+        if (i < n && !s_first[i]) s_node[i] = 0x7fffffff;
+    }
+    for (int i = n + t; i < ((n + 3) & ~3); i += TREE_SET_THREADS) s_node[i] = 0x7fffffff;  // pad to a multiple of 4
+    __syncthreads();
+    const int n4 = (n + 3) >> 2;
+#pragma unroll
+    for (int k = 0; k < ISDQN_TREE_MAX_BATCH / TREE_SET_THREADS; ++k) {
+        const int i = t + k * TREE_SET_THREADS;
+        if (i >= n || !s_first[i]) continue;
+        const int node = my_node[k];
         int rank = 0;
-        for (int j = 0; j < n; ++j) rank += (s_first[j] && s_node[j] < node) ? 1 : 0;
+#pragma unroll 4
+        for (int j4 = 0; j4 < n4; ++j4) {
+            const int4 q = reinterpret_cast<const int4*>(s_node)[j4];  // same address in every lane: LDS broadcast
+            rank += (q.x < node) + (q.y < node) + (q.z < node) + (q.w < node);
+        }
         u_node[rank] = node;
         u_delta[rank] = s_delta[i];
         atomicAdd(&s_m, 1);
