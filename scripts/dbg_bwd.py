@@ -1,6 +1,7 @@
 """Run-to-run determinism of the backward intermediates of ONE learn step from identical state (debug aid)."""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/is-dqn_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "is-dqn_amd"))
 import numpy as np, torch
 from tests.gpu_helpers import make_frame_batch, device_batch
 from slimdqn._engine import QNetEngine

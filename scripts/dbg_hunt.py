@@ -1,7 +1,8 @@
 """Hunt for rare run-to-run differences: many single learn steps from identical state; for every repeat that differs
 from the first, report which regions differ (listed in dataflow order, so the first one names the kernel)."""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/is-dqn_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "is-dqn_amd"))
 import numpy as np, torch
 from tests.gpu_helpers import make_frame_batch, device_batch
 from slimdqn._engine import QNetEngine
