@@ -54,8 +54,10 @@ struct ConvImgTraits {
 
 // Four waves; each owns all MT channel tiles of 32 output pixels.  (An eight-wave variant -- two waves per SIMD sharing
 // the image, channel halves per wave -- was measured slower: barrier-locked waves do not overlap each other.)
+// The uint8 first layer (MT = 2: 2048 workgroups of 38 KB LDS at the headline size) is asked to fit four workgroups per
+// CU (<= 128 registers): at three, its 8 workgroups per CU run as 3 + 3 + 2.
 template <int MT, int PASSES, bool U8>
-__global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvImgParams p) {
+__global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 1) void conv_fwd_img_kernel(const ConvImgParams p) {
     using T = ConvImgTraits<MT, PASSES, U8>;
     using GA = typename T::GA;
     constexpr int NT = 2;
@@ -168,8 +170,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_fwd_img_kernel(const ConvIm
                 uint32_t cx, rest, lr, c;
                 p.d_chunk.divmod((uint32_t)cq, rest, cx);
                 p.d_R.divmod(rest, c, lr);
-                int id = c == 0 ? fid[0] : c == 1 ? fid[1] : c == 2 ? fid[2] : fid[3];
-                if (c > 3) id = p.fs.frame_id(j, c);
+                // (stack <= 4 on this path, host-checked: an id lookup here would put a vmcnt(0) between the frame loads)
+                const int id = c >= 3 ? fid[3] : c == 2 ? fid[2] : c == 1 ? fid[1] : fid[0];
                 p.fs.patch8_raw(on ? id : -1, row_base + (int)lr, (int)cx * 8 - g.pad, raw[u], sh[u]);
                 dst[u] = on ? (((int)c * p.R + (int)lr) * p.Wp + (int)cx * 8) : -1;
             }
@@ -511,8 +513,7 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
                 uint32_t cx, rest, lr, c;
                 d_chunk.divmod((uint32_t)cq, rest, cx);
                 d_R.divmod(rest, c, lr);
-                int id = c == 0 ? fid[0] : c == 1 ? fid[1] : c == 2 ? fid[2] : fid[3];
-                if (c > 3) id = fs.frame_id(j, c);
+                const int id = c >= 3 ? fid[3] : c == 2 ? fid[2] : c == 1 ? fid[1] : fid[0];  // stack <= 4 (host-checked)
                 fs.patch8_raw(on ? id : -1, row_base + (int)lr, (int)cx * 8 - g.pad, raw[u], sh[u]);
                 dst[u] = on ? (((int)c * R + (int)lr) * Wp + (int)cx * 8) : -1;
             }

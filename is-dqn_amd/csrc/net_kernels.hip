@@ -900,14 +900,14 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     ConvImgParams ip;
     ip.g = conv_geom(l);
     // (two channel tiles: the kernel then alternates two accumulator sets, see conv_fwd_img_kernel)
-    const int mt = (l.cout_p <= 32 && !getenv("ISDQN_FORCE_MT4")) ? 2 : 4;
+    const int mt = l.cout_p <= 32 ? 2 : 4;
     const int passes = x3 ? (l.is_u8 ? 2 : 3) : 1;
     // pixel pitch: +8 / +16 elements so that the 16 pixels of an MFMA column tile do not share LDS banks
     // (128-byte pixel rows put them 4-5 deep on the same banks; measured model in DESIGN.md)
     ip.PP = l.is_u8 ? 0 : l.cin_p + (l.cin_p % 64 == 0 ? 16 : 8);
     const int lds = conv_img_geometry(ip.g, l.is_u8, l.cin, passes >= 3 ? 2 : 1, mt, passes >= 2 ? 2 : 1, ip.R, ip.Wp,
                                       ip.plane_elems, ip.PP);
-    if (lds > 150 * 1024 || (l.is_u8 && l.win < 8)) return ISDQN_OK;
+    if (lds > 150 * 1024 || (l.is_u8 && (l.win < 8 || l.cin > 4))) return ISDQN_OK;  // (frame ids of a stack live in 4 registers)
     ip.W = MatSrc{params + l.w_off, l.K, l.cout_p, l.K, 1};
     ip.in = act_in;
     ip.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win};
@@ -1137,7 +1137,7 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
     wp.npix_pad = round_up(l.npix, 32);
     wp.dz_plane = wp.npix_pad * wp.PA;
     const int lds = ((passes >= 2 ? 2 : 1) * wp.dz_plane + (passes >= 3 ? 2 : 1) * wp.in_plane) * 2;
-    if (lds > 150 * 1024 || (l.is_u8 && (l.win < 8 || l.cin > 16))) return ISDQN_OK;
+    if (lds > 150 * 1024 || (l.is_u8 && (l.win < 8 || l.cin > 4))) return ISDQN_OK;
     wp.d_chunk = FastDiv((uint32_t)(l.is_u8 ? Wp / 8 : l.cin_p / 8));
     wp.d_Wp = FastDiv((uint32_t)Wp);
     wp.d_R = FastDiv((uint32_t)wp.R);

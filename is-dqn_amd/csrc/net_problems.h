@@ -45,7 +45,7 @@ struct FrameSrc {
         d = ix0 - ixc;                   // < 0: left border, > 0: right border
     }
     static __device__ __forceinline__ void patch8_cvt(unsigned long long u, int d, float (&v)[8]) {
-        u = d >= 0 ? (u >> (8 * d)) : (u << (8 * (-d)));
+        u = (u >> (8 * max(d, 0))) << (8 * max(-d, 0));  // one of the two shifts is by zero (no branch)
         const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
         v[0] = (float)(lo & 0xff); v[1] = (float)((lo >> 8) & 0xff);
         v[2] = (float)((lo >> 16) & 0xff); v[3] = (float)(lo >> 24);

@@ -41,13 +41,14 @@ names = ["fill(load+convert+write)", "weights0+sync", "K loop", "epilogue issue"
 print("(layer may be e.g. Conv_1 for the forward kernel or dgrad:Conv_1 for the data-gradient kernel of that layer)")
 d = np.diff(s[:, :6], axis=1)
 ghz = float(os.environ.get("GHZ", "2.0"))
-print("start spread (cyc): p50 %.0f  p99 %.0f  max %.0f" % tuple(np.percentile(s[:, 0] - t0, [50, 99, 100])))
+# s_memtime counters are per XCD (not comparable across workgroups); the 100 MHz s_memrealtime of stamp 0 is global
+rt = (s[:, 7] - s[:, 7].min()) / 100.0
+print("workgroup start, us after the first (realtime): p10 %.2f p25 %.2f p50 %.2f p75 %.2f p90 %.2f max %.2f" % tuple(np.percentile(rt, [10, 25, 50, 75, 90, 100])))
+print("start histogram (2 us bins):", np.histogram(rt, bins=np.arange(0, rt.max() + 2, 2))[0].tolist())
 for i, n in enumerate(names):
     print(f"{n:28s} median {np.median(d[:, i]):9.0f} cyc  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}   ~{np.median(d[:, i]) / ghz / 1e3:6.2f} us @ {ghz} GHz")
 print("per-WG total median", np.median(s[:, 5] - s[:, 0]), "cyc; kernel span", span_cyc, "cyc")
 # first-round vs second-round workgroups
-late = (s[:, 0] - t0) > 0.3 * span_cyc
-print("workgroups starting late (2nd round):", late.sum())
 # optional step-level stamps (diagnostic build only): second row block
 s2 = st.cpu().numpy().reshape(nwg, 8)
 g = len(s)
