@@ -23,12 +23,24 @@ __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int has_relu,
                                                          float* __restrict__ act, float* __restrict__ z, int z_rows) {
-    extern __shared__ float s_row[];
+    extern __shared__ float s_row[];  // [3][Fp]: the summed row, gamma, beta
     __shared__ float s_red[2][4];
     const int row = blockIdx.x, tid = threadIdx.x;
+    float* s_g = s_row + Fp;
+    float* s_b = s_row + 2 * Fp;
     float s1 = 0.f, s2 = 0.f;
-    // two adjacent columns per thread (Fp is a multiple of 8: 8-byte loads), 16 slabs in flight, fixed summation order
+    // two adjacent columns per thread (Fp is a multiple of 8: 8-byte loads), 16 slabs in flight, fixed summation order.
+    // bias / gamma / beta of the two columns are requested FIRST and travel under the slab loads: a workgroup lives
+    // for a few microseconds, and three dependent round trips behind the sums were a third of that.
     for (int c = 2 * tid; c < Fp; c += 512) {
+        float par[3][2];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float* src = w == 0 ? bias : w == 1 ? gamma : beta;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                par[w][e] = *(const ISDQN_GLOBAL float*)((src != nullptr && c + e < F) ? src + c + e : zero_chunk());
+        }
         float v0 = 0.f, v1 = 0.f;
         const float* p = slabs + (int64_t)row * Fp + c;
         int s = 0;
@@ -47,10 +59,12 @@ __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict
 #pragma unroll
             for (int u = 0; u < 16; ++u) { v0 += (s + u < n_slabs) ? t[u].x : 0.f; v1 += (s + u < n_slabs) ? t[u].y : 0.f; }
         }
-        v0 = c < F ? v0 + bias[c] : 0.f;
-        v1 = c + 1 < F ? v1 + bias[c + 1] : 0.f;
+        v0 = c < F ? v0 + par[0][0] : 0.f;
+        v1 = c + 1 < F ? v1 + par[0][1] : 0.f;
         s_row[c] = v0;
         s_row[c + 1] = v1;
+        s_g[c] = par[1][0]; s_g[c + 1] = par[1][1];
+        s_b[c] = par[2][0]; s_b[c + 1] = par[2][1];
         s1 += v0 + v1;
         s2 += v0 * v0 + v1 * v1;
     }
@@ -72,17 +86,19 @@ __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict
         rstd = rsqrtf(var + 1e-6f);
     }
     for (int c0 = 2 * tid; c0 < Fp; c0 += 512) {
+        float y2[2], v2[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int c = c0 + e;
-            float v = s_row[c];  // written by this same thread
+            const float v = s_row[c];  // (row, gamma, beta: written by this same thread)
             float y = v;
-            if (gamma != nullptr && c < F) y = (v - mean) * (rstd * gamma[c]) + beta[c];
+            if (gamma != nullptr && c < F) y = (v - mean) * (rstd * s_g[c]) + s_b[c];
             if (has_relu) y = fmaxf(y, 0.f);
             if (c >= F) y = 0.f;
-            act[(int64_t)row * Fp + c] = y;
-            if (row < z_rows) z[(int64_t)row * Fp + c] = v;
+            y2[e] = y; v2[e] = v;
         }
+        *reinterpret_cast<float2*>(act + (int64_t)row * Fp + c0) = make_float2(y2[0], y2[1]);
+        if (row < z_rows) *reinterpret_cast<float2*>(z + (int64_t)row * Fp + c0) = make_float2(v2[0], v2[1]);
     }
 }
 
@@ -784,6 +800,14 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* _
     const int64_t i = ((int64_t)(blockIdx.x - en.block_start) * 16 + pos) * 4;
     const bool on = i < en.size;
     float4 g = float4{0.f, 0.f, 0.f, 0.f};
+    // the updating lanes request their moments and parameters now: they arrive under the slab reduction
+    const int64_t o = en.p_off + i;
+    float4 pm = g, pv = g, pp = g;
+    if (on && sl == 0) {
+        pm = *reinterpret_cast<const float4*>(m + o);
+        pv = *reinterpret_cast<const float4*>(v + o);
+        pp = *reinterpret_cast<const float4*>(p + o);
+    }
     if (on) {
         int s = sl;
         for (; s + 3 * 16 < en.n_slabs; s += 4 * 16) {
@@ -807,10 +831,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* _
         const float4 h = s_g[k][pos];
         g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
     }
-    const int64_t o = en.p_off + i;
     if (grad_out != nullptr) *reinterpret_cast<float4*>(grad_out + o) = g;
-    float4 pm = *reinterpret_cast<float4*>(m + o), pv = *reinterpret_cast<float4*>(v + o);
-    float4 pp = *reinterpret_cast<float4*>(p + o);
     float* gp = &g.x; float* mp = &pm.x; float* vp = &pv.x; float* xp = &pp.x;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1024,7 +1045,7 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInpu
     }
     if (rc) return rc;
     int ns = effective_splits(l.in_unpadded_ld ? l.in_f : l.K, l.fwd_splits);
-    hipLaunchKernelGGL(dense_post_kernel, dim3(rows), dim3(256), l.out_p * sizeof(float), st, slab, ns, slab_stride,
+    hipLaunchKernelGGL(dense_post_kernel, dim3(rows), dim3(256), 3 * l.out_p * sizeof(float), st, slab, ns, slab_stride,
                        rows, l.out_f, l.out_p, params + l.b_off, l.has_ln ? params + l.g_off : nullptr,
                        l.has_ln ? params + l.be_off : nullptr, l.has_relu, act, z, z_rows);
     ISDQN_HIP_CHECK(hipGetLastError());
