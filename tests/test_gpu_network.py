@@ -34,6 +34,46 @@ def _flat_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
 
 
+# other observation geometries: (obs (h, w, stack), feats, K, A, B)
+GEOMETRIES = [
+    # a 6-frame stack: the image-resident uint8 kernels hold at most 4 frame ids, so the first layer takes the generic engine
+    pytest.param(((44, 44, 6), (7, 9, 11, 13), 2, 3, 5), id="44x44x6-generic-first-layer"),
+    # non-square frames, 2-frame stack (image-resident, padded width not a multiple of the stride)
+    pytest.param(((52, 60, 2), (16, 20, 12, 24), 3, 4, 6), id="52x60x2"),
+    pytest.param(((84, 84, 1), (32, 64, 64, 64), 2, 6, 4), id="84x84x1"),
+]
+
+
+@pytest.mark.parametrize("geo", GEOMETRIES)
+def test_other_observation_geometries(geo):
+    """Forward, loss terms, first-step gradients and one Adam step against the oracle for observation shapes other
+    than the Atari 84x84x4 (dqn.py:49-72 is geometry-agnostic: SAME padding, any stack depth)."""
+    obs, feats, K, A, B = geo
+    tol = TOL["bf16x3"]
+    h, w, stack = obs
+    oracle, eng, params = make_pair(feats, K, A, B, obs=obs, seed=5)
+    frames, ids, action, reward, terminal, ref = make_frame_batch(B, A, seed=17, h=h, w=w, stack=stack)
+    batch = device_batch(eng, frames, ids, action, reward, terminal)
+    all_q = oracle.apply(oracle.params, torch.cat((torch.tensor(ref.state), torch.tensor(ref.next_state)))).detach().numpy()
+    flat_ids = np.concatenate([ids[:, :stack], ids[:, stack:]], 0).copy()
+    q = eng.forward(frames=batch._keep[0], frame_stride=frames.shape[1], frame_ids=torch.from_numpy(flat_ids).cuda(), n_rows=2 * B)
+    q = q.cpu().numpy().reshape(2 * B, 1 + K, A)
+    assert np.abs(q - all_q).max() < tol["q"], f"forward max err {np.abs(q - all_q).max()}"
+    o_q, o_t, o_td = oracle.loss_terms(oracle.params, ref)
+    o_grads, _ = oracle.grads(oracle.params, ref)
+    _, _, o_losses = oracle.learn_on_batch(oracle.params, oracle.optimizer_state, ref)
+    grad = torch.zeros_like(eng.params)
+    losses = eng.learn_on_batch(batch, grad_out=grad).cpu().numpy()
+    assert np.abs(eng.targets.cpu().numpy() - o_t.detach().numpy()).max() < tol["q"]
+    assert np.abs(eng.q_values.cpu().numpy() - o_q.detach().numpy()).max() < tol["q"]
+    assert np.abs(losses - o_losses).max() < tol["loss"] * max(1.0, np.abs(o_losses).max())
+    g = eng.internal_to_flax_grads(grad)
+    for mod in o_grads:
+        for leaf in o_grads[mod]:
+            e = _flat_err(g[mod][leaf], o_grads[mod][leaf].numpy())
+            assert e < tol["grad"], f"grad {mod}/{leaf}: rel err {e}"
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("cfg", CONFIGS)
 def test_forward_loss_grad_adam(cfg, precision):
