@@ -11,6 +11,18 @@
 
 namespace isdqn {
 
+// b^t for the Adam bias corrections 1 - b^t (optax.adam, isdqn.py:46): exponentiation by squaring, at most 62 double
+// multiplies (relative error ~1e-15).  The library pow() is thousands of instructions on ONE lane -- 10-20 us -- and
+// the kernel that owns the step counter lasts as long as that lane.
+__device__ inline double pow_int(double b, int t) {
+    double r = 1.0, x = b;
+    for (unsigned u = (unsigned)t; u != 0; u >>= 1) {
+        if (u & 1u) r *= x;
+        x *= x;
+    }
+    return r;
+}
+
 // =============================================================================================
 // Row-wise kernels
 // =============================================================================================
@@ -412,127 +424,236 @@ struct HeadChainParams {
     int* adam_count;
     float b1, b2;
     float* adam_consts;
+    long long* stamps;  // profiling only (isdqn_debug_set_stamps "head_chain"): [workgroup][8] phase boundaries
 };
 
-constexpr int HC_MAX_S = 4;     // transitions per workgroup (online + next rows: half of a 16-row MFMA tile)
-constexpr int HC_MAX_COLS = 4;  // hidden width up to 1024 (columns per thread: template parameter COLS)
+// HC_MAX_S (net_plan.h): transitions per workgroup.  The kernel is instruction-issue bound (one wave per SIMD, a few
+// thousand instructions executed once), and the target / data-gradient / LayerNorm phases scale with S: two
+// transitions on 128 workgroups beat four on 64 although the head weights are then read twice as often from L2.
+constexpr int HC_MAX_COLS = 4;  // hidden width up to HC_THREADS * 4 (columns per thread: template parameter COLS)
+// Eight waves: the kernel executes a few thousand instructions ONCE per wave, so it is bound by instruction issue and
+// its dependency stalls; two waves per SIMD interleave, and each owns half the K-steps / columns.
+constexpr int HC_THREADS = 512, HC_WAVES = HC_THREADS / 64;
+constexpr int HC_KU = 16 / HC_WAVES;  // K-steps per wave and work item (an item covers 16 K-steps)
 
 __host__ __device__ inline int head_chain_pitch(int Fp) { return (Fp + 31) / 32 * 32 + 8; }
 static inline int head_chain_lds_bytes(int Fp, int Op, int K, int passes) {
     const int PA = head_chain_pitch(Fp);
-    return (passes >= 2 ? 2 : 1) * 16 * PA * 2 + (4 * 16 * Op + 16 * Op + HC_MAX_S * Op) * 4 + HC_MAX_S * K * 12 +
-           4 * HC_MAX_S * 2 * 4 + 64;
+    return (passes >= 2 ? 2 : 1) * 16 * PA * 2 + (HC_WAVES * 16 * Op + 16 * Op + HC_MAX_S * Op + Op) * 4 + HC_MAX_S * K * 8 +
+           HC_WAVES * HC_MAX_S * 2 * 4 + 64;
 }
 
 template <int PASSES, int COLS>
-__global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p) {
+__global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainParams p) {
     extern __shared__ __attribute__((aligned(16))) char hc_smem[];
     const int PA = head_chain_pitch(p.Fp);
     constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
     __bf16* a_hi = reinterpret_cast<__bf16*>(hc_smem);
     __bf16* a_lo = a_hi + 16 * PA;
-    float* qpart = reinterpret_cast<float*>(a_hi + A_PLANES * 16 * PA);  // [4][16][Op]
-    float* s_q = qpart + 4 * 16 * p.Op;                                  // [16][Op]
+    float* qpart = reinterpret_cast<float*>(a_hi + A_PLANES * 16 * PA);  // [HC_WAVES][16][Op]
+    float* s_q = qpart + HC_WAVES * 16 * p.Op;                                  // [16][Op]
     float* s_dq = s_q + 16 * p.Op;                                       // [HC_MAX_S][Op]
     float* s_d = s_dq + HC_MAX_S * p.Op;                                 // [HC_MAX_S][K]
     float* s_td = s_d + HC_MAX_S * p.K;
-    int* s_wrow = reinterpret_cast<int*>(s_td + HC_MAX_S * p.K);
-    float* s_red = reinterpret_cast<float*>(s_wrow + HC_MAX_S * p.K);    // [4][HC_MAX_S][2]
+    float* s_red = s_td + HC_MAX_S * p.K;                                // [HC_WAVES][HC_MAX_S][2]
+    float* s_bias = s_red + HC_WAVES * HC_MAX_S * 2;                            // [Op]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define HC_STAMP(i)                                                                                     \
+    if (p.stamps != nullptr && threadIdx.x == 0) {                                                     \
+        p.stamps[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime();              \
+        if ((i) == 0) p.stamps[(int64_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    }
+    HC_STAMP(0);
     const int S = p.S, b0 = (int)blockIdx.x * S;
     const int Fp = p.Fp, Op = p.Op, K = p.K, A = p.A;
 
     if (blockIdx.x == 0 && tid == 0) {
         int t = *p.adam_count + 1;
         *p.adam_count = t;
-        p.adam_consts[0] = (float)(1.0 - pow((double)p.b1, (double)t));
-        p.adam_consts[1] = (float)(1.0 - pow((double)p.b2, (double)t));
+        p.adam_consts[0] = (float)(1.0 - pow_int((double)p.b1, t));
+        p.adam_consts[1] = (float)(1.0 - pow_int((double)p.b2, t));
     }
 
-    // ---- hidden rows -> LDS (bf16 hi/lo, rows >= 2S and columns >= Fp zero) ----
-    {
-        const int cpr = (PA - 8) / 8;
-        for (int c = tid; c < 16 * cpr; c += 256) {
+    // Every global load of this kernel is requested a phase before it is needed, and nothing touches a loaded
+    // register where it is requested: 64 workgroups on 64 CUs run a chain of short phases, the data were last written
+    // from other XCDs (a first touch costs ~4000 cycles), and a phase that starts with its own round trip costs
+    // more than its work.
+    // ---- hidden rows -> LDS (bf16 hi/lo; columns >= Fp zero): two chunks per thread in flight.  Only the 2S rows of
+    //      this workgroup are staged: MFMA output rows depend on their own A row only, and nothing reads the q rows
+    //      of the remaining tile rows, so those LDS rows stay as they are ----
+    const int cpr = (PA - 8) / 8, n_chunks = 2 * S * cpr;
+    float hv[2][8];
+    int hdst[2];
+    auto request_rows = [&](int cb) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = cb + u * HC_THREADS + tid;
             const int row = c / cpr, cc = c - row * cpr;
             const int smp = row < S ? row : row - S;
-            const bool ok = row < 2 * S && b0 + smp < p.B && cc * 8 < Fp;
+            const bool ok = c < n_chunks && b0 + smp < p.B && cc * 8 < Fp;
             const int64_t grow = row < S ? (int64_t)(b0 + smp) : (int64_t)p.B + b0 + smp;
-            float v[8];
-            load8_aligned(ok ? p.act + (grow * Fp + cc * 8) : zero_chunk(), v);
+            load8_aligned(ok ? p.act + (grow * Fp + cc * 8) : zero_chunk(), hv[u]);
+            hdst[u] = c < n_chunks ? row * PA + cc * 8 : -1;
+        }
+    };
+    auto stage_rows = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
             bf16x8 hi, lo;
             if constexpr (PASSES >= 2) {
-                split8(v, hi, lo);
-                *reinterpret_cast<bf16x8*>(a_lo + row * PA + cc * 8) = lo;
+                split8(hv[u], hi, lo);
+                if (hdst[u] >= 0) *reinterpret_cast<bf16x8*>(a_lo + hdst[u]) = lo;
             } else {
-                round8(v, hi);
+                round8(hv[u], hi);
             }
-            *reinterpret_cast<bf16x8*>(a_hi + row * PA + cc * 8) = hi;
+            if (hdst[u] >= 0) *reinterpret_cast<bf16x8*>(a_hi + hdst[u]) = hi;
         }
-        for (int i = tid; i < HC_MAX_S * Op; i += 256) s_dq[i] = 0.f;
-    }
-    __syncthreads();
+    };
+    request_rows(0);
 
-    // ---- q = a W^T : wave w takes K-steps w, w+4, ... of every 16-column tile; the W fragments of two column
-    //      tiles x four K-steps are loaded as one batch so that their L2 latencies overlap ----
+    // ---- q = a W^T work items, see below; the first batch of W fragments is requested behind the hidden rows ----
+    const int nkt = (PA - 8) / 32, NT = (Op + 15) / 16;
+    const int nks = (nkt + 15) / 16, n_items = ((NT + 1) / 2) * nks;
+    const int kg8 = (lane >> 4) * 8;
+    const int arow = (lane & 15) * PA + kg8;
+    auto issue_w = [&](float (&v)[2][HC_KU][8], int item) {
+        const int pair = item / nks, ksb = wave + 16 * (item - pair * nks);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < HC_KU; ++u) {
+                const int o = (pair * 2 + t) * 16 + (lane & 15), ks = ksb + HC_WAVES * u;
+                const bool ok = item < n_items && o < p.O && ks < nkt && ks * 32 + kg8 < Fp;
+                load8_aligned(ok ? p.W + (int64_t)o * Fp + ks * 32 + kg8 : zero_chunk(), v[t][u]);
+            }
+    };
+    float wv0[2][HC_KU][8], wv1[2][HC_KU][8];
+    issue_w(wv0, 0);
+
+    // ---- operands of the later phases (raw: converted where they are used) ----
+    int act[HC_MAX_S];  // action of the S transitions (selects the head rows the data gradient reads)
+#pragma unroll
+    for (int s = 0; s < HC_MAX_S; ++s) act[s] = *(const ISDQN_GLOBAL int*)((s < S && b0 + s < p.B) ? (const void*)(p.action + b0 + s) : zero_chunk());
+    float td_r;          // reward, terminal flag of this thread's (transition, head) pair
+    uint8_t td_term;
     {
-        const int nkt = (PA - 8) / 32, NT = (Op + 15) / 16;
-        const int kg8 = (lane >> 4) * 8;
-        const int arow = (lane & 15) * PA + kg8;
-        for (int nt = 0; nt < NT; nt += 2) {
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            asm volatile("s_nop 7" : "+a"(acc[0]), "+a"(acc[1]));  // accumulator init (VALU) -> asm MFMA: no compiler padding
-            for (int ksb = wave; ksb < nkt; ksb += 16) {
-                float v[2][4][8];
+        const int s = tid / K;
+        const bool ok = tid < S * K && b0 + s < p.B;
+        td_r = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.reward + b0 + s) : zero_chunk());
+        td_term = *(const ISDQN_GLOBAL uint8_t*)(ok ? (const void*)(p.terminal + b0 + s) : zero_chunk());
+    }
+    const float bias_v = *(const ISDQN_GLOBAL float*)(tid < p.O ? (const void*)(p.bias + tid) : zero_chunk());
+    float zv[HC_MAX_S][COLS], ga[COLS], be[COLS];
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+    for (int s = 0; s < HC_MAX_S; ++s)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int o = (nt + t) * 16 + (lane & 15), ks = ksb + 4 * u;
-                        const bool ok = o < p.O && ks < nkt && ks * 32 + kg8 < Fp;
-                        load8_aligned(ok ? p.W + (int64_t)o * Fp + ks * 32 + kg8 : zero_chunk(), v[t][u]);
-                    }
+        for (int j = 0; j < COLS; ++j) {
+            const int c = tid + j * HC_THREADS;
+            const bool ok = s < S && b0 + s < p.B && c < p.F;
+            zv[s][j] = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.z + (int64_t)(b0 + s) * Fp + c) : zero_chunk());
+        }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ks = min(ksb + 4 * u, nkt - 1);  // past the end: B is zero, A only has to be finite
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_hi + arow + ks * 32);
-                    bf16x8 al;
-                    if constexpr (PASSES >= 2) al = *reinterpret_cast<const bf16x8*>(a_lo + arow + ks * 32);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        bf16x8 bh, bl;
-                        if constexpr (PASSES >= 2) {
-                            split8(v[t][u], bh, bl);
-                            // VALU-written operands -> asm MFMA: no compiler hazard handling, and the pad must be tied
-                            // to the operands or the scheduler sinks the conversions below it
-                            asm volatile("s_nop 4" : "+v"(bh), "+v"(bl));
-                            if constexpr (PASSES >= 3)
-                                mfma_acc(acc[t], ah, bl);
-                            mfma_acc(acc[t], al, bh);
-                        } else {
-                            round8(v[t][u], bh);
-                            asm volatile("s_nop 4" : "+v"(bh));
-                        }
-                        mfma_acc(acc[t], ah, bh);
-                    }
-                }
-                mfma_drain(ksb + 16 >= nkt);
+    for (int j = 0; j < COLS; ++j) {
+        const int c = tid + j * HC_THREADS;
+        const bool ok = p.gamma != nullptr && c < p.F;
+        ga[j] = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.gamma + c) : zero_chunk());
+        be[j] = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.beta + c) : zero_chunk());
+    }
+
+    stage_rows();
+    for (int cb = 2 * HC_THREADS; cb < n_chunks; cb += 2 * HC_THREADS) {  // (2S rows of more than 2048 / (2S) columns)
+        request_rows(cb);
+        stage_rows();
+    }
+    for (int i = tid; i < HC_MAX_S * Op; i += HC_THREADS) s_dq[i] = 0.f;
+    if (tid < Op) s_bias[tid] = bias_v;
+    for (int o = tid + HC_THREADS; o < Op; o += HC_THREADS) s_bias[o] = o < p.O ? p.bias[o] : 0.f;  // (more outputs than threads)
+    __syncthreads();  // hidden rows staged
+    HC_STAMP(1);  // hidden rows staged
+
+    // ---- q = a W^T : wave w takes K-steps w, w+16, ... of every pair of 16-column tiles.  A work item is (tile pair,
+    //      K-step group): its W fragments (two tiles x four K-steps) are one batch of loads, and the batch of the NEXT
+    //      item is in flight while this one is multiplied ----
+    {
+        f32x4 acc[2];
+        auto run_item = [&](float (&v)[2][HC_KU][8], int item) {
+            const int pair = item / nks, ksi = item - pair * nks, ksb = wave + 16 * ksi;
+            if (ksi == 0) {
+                acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                asm volatile("s_nop 7" : "+a"(acc[0]), "+a"(acc[1]));  // accumulator init (VALU) -> asm MFMA: no compiler padding
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int o = (nt + t) * 16 + (lane & 15);
-                if (o < Op) {
+            for (int u = 0; u < HC_KU; ++u) {
+                const int ks = min(ksb + HC_WAVES * u, nkt - 1);  // past the end: B is zero, A only has to be finite
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_hi + arow + ks * 32);
+                bf16x8 al;
+                if constexpr (PASSES >= 2) al = *reinterpret_cast<const bf16x8*>(a_lo + arow + ks * 32);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) qpart[(wave * 16 + (lane >> 4) * 4 + r) * Op + o] = acc[t][r];
+                for (int t = 0; t < 2; ++t) {
+                    bf16x8 bh, bl;
+                    if constexpr (PASSES >= 2) {
+                        split8(v[t][u], bh, bl);
+                        // VALU-written operands -> asm MFMA: no compiler hazard handling, and the pad must be tied
+                        // to the operands or the scheduler sinks the conversions below it
+                        asm volatile("s_nop 4" : "+v"(bh), "+v"(bl));
+                        if constexpr (PASSES >= 3)
+                            mfma_acc(acc[t], ah, bl);
+                        mfma_acc(acc[t], al, bh);
+                    } else {
+                        round8(v[t][u], bh);
+                        asm volatile("s_nop 4" : "+v"(bh));
+                    }
+                    mfma_acc(acc[t], ah, bh);
                 }
             }
+            const bool last = ksi + 1 == nks;
+            mfma_drain(last);
+            if (last) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int o = (pair * 2 + t) * 16 + (lane & 15);
+                    if (o < Op) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) qpart[(wave * 16 + (lane >> 4) * 4 + r) * Op + o] = acc[t][r];
+                    }
+                }
+            }
+        };
+        for (int item = 0; item < n_items; item += 2) {
+            issue_w(wv1, item + 1);  // (past the last item: zero block)
+            run_item(wv0, item);
+            issue_w(wv0, item + 2);
+            if (item + 1 < n_items) run_item(wv1, item + 1);
         }
     }
+
+    // ---- data-gradient rows: head row (1 + k) * A + action of every (transition, head), four heads per batch; the
+    //      first batch is requested here and travels under the target / TD phase ----
+    auto issue_rows = [&](float (&w)[HC_MAX_S][4][COLS], int k0) {
+#pragma unroll
+        for (int s = 0; s < HC_MAX_S; ++s)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool on = s < S && k0 + u < K;
+                const float* wr = p.W + (int64_t)(on ? (1 + k0 + u) * A + act[s] : 0) * Fp;
+#pragma unroll
+                for (int j = 0; j < COLS; ++j) {
+                    const int c = tid + j * HC_THREADS;
+                    w[s][u][j] = *(const ISDQN_GLOBAL float*)(wr + (c < p.F ? c : 0));
+                }
+            }
+    };
+    HC_STAMP(2);  // head GEMM done (this wave)
+    float wr0[HC_MAX_S][4][COLS], wr1[HC_MAX_S][4][COLS];
+    issue_rows(wr0, 0);
     __syncthreads();
-    for (int i = tid; i < 16 * Op; i += 256) {
+    for (int i = tid; i < 2 * S * Op; i += HC_THREADS) {  // (tile rows 2S..15 are nobody's)
         const int o = i % Op;
-        float v = qpart[i] + qpart[16 * Op + i] + qpart[32 * Op + i] + qpart[48 * Op + i];
-        s_q[i] = o < p.O ? v + p.bias[o] : 0.f;
+        float v = qpart[i];
+#pragma unroll
+        for (int w = 1; w < HC_WAVES; ++w) v += qpart[w * 16 * Op + i];  // fixed order
+        s_q[i] = o < p.O ? v + s_bias[o] : 0.f;
     }
     __syncthreads();
 
@@ -544,13 +665,14 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
         float d = 0.f, td = 0.f;
         int a = 0;
         if (b < p.B) {
-            a = p.action[b];
-            const float r = p.reward[b], nt = 1.f - (float)p.terminal[b];
+            a = act[0];
+#pragma unroll
+            for (int i = 1; i < HC_MAX_S; ++i) a = s == i ? act[i] : a;
             const float qv = s_q[s * Op + (1 + k) * A + a];
             const float* nq = s_q + (S + s) * Op + k * A;
             float mx = nq[0];
             for (int j = 1; j < A; ++j) mx = fmaxf(mx, nq[j]);
-            const float tg = r + nt * p.gamma_n * mx;
+            const float tg = td_r + (1.f - (float)td_term) * p.gamma_n * mx;
             d = qv - tg;
             td = d * d;
             if (p.q_values) p.q_values[(int64_t)b * K + k] = qv;
@@ -559,15 +681,14 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
         const float dd = 2.f * d * inv_b;
         s_d[tid] = dd;
         s_td[tid] = td;
-        s_wrow[tid] = (1 + k) * A + a;
         s_dq[s * Op + (1 + k) * A + a] = dd;
     }
     __syncthreads();
-    for (int i = tid; i < S * Op; i += 256) {
+    for (int i = tid; i < S * Op; i += HC_THREADS) {
         const int s = i / Op;
         if (b0 + s < p.B) p.dout[(int64_t)b0 * Op + i] = s_dq[i];
     }
-    for (int c = tid; c < Op; c += 256) {
+    for (int c = tid; c < Op; c += HC_THREADS) {
         float sum = 0.f;
         for (int s = 0; s < S; ++s) sum += s_dq[s * Op + c];
         p.dbh_part[(int64_t)blockIdx.x * Op + c] = sum;
@@ -583,55 +704,36 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
         p.priorities[b0 + tid] = sqrt((double)(sum / (float)K) + 1e-10);
     }
 
-    // ---- da = dL/dq W (K row-AXPYs per transition), then the LayerNorm/ReLU backward of the hidden row ----
-    float da[HC_MAX_S][COLS], zv[HC_MAX_S][COLS];
+    HC_STAMP(3);  // targets / TD / small stores issued
+    // ---- da = dL/dq W (K row-AXPYs per transition, heads in ascending order), then the LayerNorm/ReLU backward of
+    //      the hidden row ----
+    float da[HC_MAX_S][COLS];
 #pragma unroll
     for (int s = 0; s < HC_MAX_S; ++s)
 #pragma unroll
-        for (int j = 0; j < COLS; ++j) da[s][j] = zv[s][j] = 0.f;
-#pragma unroll
-    for (int s = 0; s < HC_MAX_S; ++s)
-        if (s < S && b0 + s < p.B) {
-#pragma unroll
-            for (int j = 0; j < COLS; ++j) {
-                const int c = tid + j * 256;
-                if (c < p.F) zv[s][j] = p.z[(int64_t)(b0 + s) * Fp + c];
-            }
-        }
-    for (int k0 = 0; k0 < K; k0 += 4) {  // 4 heads x S transitions x COLS columns of W rows in flight
-        float w[HC_MAX_S][4][COLS], dd[HC_MAX_S][4];
+        for (int j = 0; j < COLS; ++j) da[s][j] = 0.f;
+    auto axpy_rows = [&](const float (&w)[HC_MAX_S][4][COLS], int k0) {
 #pragma unroll
         for (int s = 0; s < HC_MAX_S; ++s)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool on = s < S && k0 + u < K;
-                const int idx = on ? s * K + k0 + u : 0;
-                dd[s][u] = on ? s_d[idx] : 0.f;
-                const float* wr = p.W + (int64_t)s_wrow[idx] * Fp;
+                const float dd = on ? s_d[s * K + k0 + u] : 0.f;
 #pragma unroll
-                for (int j = 0; j < COLS; ++j) {
-                    const int c = tid + j * 256;
-                    w[s][u][j] = wr[c < p.F ? c : 0];
-                }
+                for (int j = 0; j < COLS; ++j) da[s][j] += dd * w[s][u][j];
             }
-#pragma unroll
-        for (int s = 0; s < HC_MAX_S; ++s)
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < COLS; ++j) da[s][j] += dd[s][u] * w[s][u][j];
+    };
+    for (int k0 = 0; k0 < K; k0 += 8) {  // 4 heads x S transitions x COLS columns of W rows per batch, two batches in flight
+        issue_rows(wr1, k0 + 4);
+        axpy_rows(wr0, k0);
+        issue_rows(wr0, k0 + 8);
+        if (k0 + 4 < K) axpy_rows(wr1, k0 + 4);
     }
+    HC_STAMP(4);  // data-gradient rows accumulated
     float dg[COLS], db[COLS], dbias[COLS];
 #pragma unroll
     for (int j = 0; j < COLS; ++j) dg[j] = db[j] = dbias[j] = 0.f;
     if (p.gamma != nullptr) {
-        float ga[COLS], be[COLS];
-#pragma unroll
-        for (int j = 0; j < COLS; ++j) {
-            const int c = tid + j * 256;
-            ga[j] = c < p.F ? p.gamma[c] : 0.f;
-            be[j] = c < p.F ? p.beta[c] : 0.f;
-        }
         const float inv_c = 1.f / (float)p.F;
         float r1[HC_MAX_S], r2[HC_MAX_S];
         auto block_sum2 = [&]() {  // r1[s], r2[s] summed over the workgroup
@@ -652,9 +754,13 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < HC_MAX_S; ++s) {
-                r1[s] = s_red[s * 2] + s_red[(HC_MAX_S + s) * 2] + s_red[(2 * HC_MAX_S + s) * 2] + s_red[(3 * HC_MAX_S + s) * 2];
-                r2[s] = s_red[s * 2 + 1] + s_red[(HC_MAX_S + s) * 2 + 1] + s_red[(2 * HC_MAX_S + s) * 2 + 1] +
-                        s_red[(3 * HC_MAX_S + s) * 2 + 1];
+                r1[s] = s_red[s * 2];
+                r2[s] = s_red[s * 2 + 1];
+#pragma unroll
+                for (int w = 1; w < HC_WAVES; ++w) {  // fixed order
+                    r1[s] += s_red[(w * HC_MAX_S + s) * 2];
+                    r2[s] += s_red[(w * HC_MAX_S + s) * 2 + 1];
+                }
             }
         };
 #pragma unroll
@@ -675,7 +781,7 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
             r1[s] = r2[s] = 0.f;
 #pragma unroll
             for (int j = 0; j < COLS; ++j) {
-                const int c = tid + j * 256;
+                const int c = tid + j * HC_THREADS;
                 const bool ok = c < p.F && s < S && b0 + s < p.B;
                 const float xh = (zv[s][j] - mean[s]) * rstd[s];
                 const float y = xh * ga[j] + be[j];
@@ -696,7 +802,7 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
             if (s < S && b0 + s < p.B) {
 #pragma unroll
                 for (int j = 0; j < COLS; ++j) {
-                    const int c = tid + j * 256;
+                    const int c = tid + j * HC_THREADS;
                     if (c < Fp) {
                         const float o = c < p.F ? rstd[s] * (da[s][j] - m1 - zv[s][j] * m2) : 0.f;
                         dbias[j] += o;
@@ -711,7 +817,7 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
             if (s < S && b0 + s < p.B) {
 #pragma unroll
                 for (int j = 0; j < COLS; ++j) {
-                    const int c = tid + j * 256;
+                    const int c = tid + j * HC_THREADS;
                     if (c < Fp) {
                         const float o = (c < p.F && zv[s][j] > 0.f) ? da[s][j] : 0.f;
                         dbias[j] += o;
@@ -723,7 +829,7 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
     }
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
-        const int c = tid + j * 256;
+        const int c = tid + j * HC_THREADS;
         if (c < Fp) {
             float* pp = p.part + (int64_t)blockIdx.x * 3 * Fp;
             pp[c] = dg[j];
@@ -731,6 +837,8 @@ __global__ __launch_bounds__(256) void head_chain_kernel(const HeadChainParams p
             pp[2 * Fp + c] = dbias[j];
         }
     }
+    HC_STAMP(5);  // LayerNorm backward done, stores issued
+#undef HC_STAMP
 }
 
 // losses[k] = mean_b td (isdqn.py:103), optional running sum (update_online_params' cumulated_losses,
@@ -742,33 +850,42 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
                                                             int* adam_count, float b1, float b2,
                                                             float* __restrict__ adam_consts) {
     const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
-    // 16 lanes share one output: strided partial sums, then a fixed shuffle tree
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const int k = k0 + grp;
-        float s = 0.f;
-        if (k < K)
-            for (int i = sub; i < n_blk; i += 16) s += loss_part[(int64_t)i * K + k];
-        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (k < K && sub == 0) {
+    // One workgroup per 16 outputs (blocks [0, ceil(K/16)): losses, the rest: head-bias columns).  16 lanes share one
+    // output: strided partial sums (eight loads in flight, added in index order), then a fixed shuffle tree.
+    const int nkb = (K + 15) / 16;
+    const bool is_loss = (int)blockIdx.x < nkb;
+    const int col = (is_loss ? (int)blockIdx.x : (int)blockIdx.x - nkb) * 16 + grp;
+    const int ncol = is_loss ? K : nha_p;
+    const float* src = is_loss ? loss_part : dbh_part;
+    if (!is_loss && dbh == nullptr) return;
+    float s = 0.f;
+    if (col < ncol)
+        for (int i0 = sub; i0 < n_blk; i0 += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 16;
+                v[u] = i < n_blk ? src[(int64_t)i * ncol + col] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (col < ncol && sub == 0) {
+        if (is_loss) {
             s /= (float)B;
-            losses[k] = s;
-            if (loss_accum != nullptr) loss_accum[k] += s;
+            losses[col] = s;
+            if (loss_accum != nullptr) loss_accum[col] += s;
+        } else {
+            dbh[col] = s;
         }
     }
-    if (dbh != nullptr)
-        for (int c0 = 0; c0 < nha_p; c0 += 16) {
-            const int c = c0 + grp;
-            float s = 0.f;
-            if (c < nha_p)
-                for (int i = sub; i < n_blk; i += 16) s += dbh_part[(int64_t)i * nha_p + c];
-            for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
-            if (c < nha_p && sub == 0) dbh[c] = s;
-        }
+    if (blockIdx.x != 0) return;
     if (adam_count != nullptr && tid == 0) {
         int t = *adam_count + 1;
         *adam_count = t;
-        adam_consts[0] = (float)(1.0 - pow((double)b1, (double)t));
-        adam_consts[1] = (float)(1.0 - pow((double)b2, (double)t));
+        adam_consts[0] = (float)(1.0 - pow_int((double)b1, t));
+        adam_consts[1] = (float)(1.0 - pow_int((double)b2, t));
     }
 }
 
@@ -1422,9 +1539,9 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     int hc_S = 0, hc_wg = 0;
     static const bool hc_disabled = getenv("ISDQN_NO_HEAD_CHAIN") != nullptr;
     if (learn && !hc_disabled && P.n_layers >= 2 && hid.kind == 1 && !hid.is_head && hid.has_relu &&
-        hid.out_p <= 256 * HC_MAX_COLS && hid.out_p % 8 == 0) {
+        hid.out_p <= HC_THREADS * HC_MAX_COLS && hid.out_p % 8 == 0) {
         const int n_wg = ceil_div(B, HC_MAX_S);
-        if (n_wg <= hid.part_rows && HC_MAX_S * K <= 256 &&
+        if (n_wg <= hid.part_rows && HC_MAX_S * K <= HC_THREADS &&
             head_chain_lds_bytes(hid.out_p, P.nha_p, K, x3 ? 3 : 1) <= 150 * 1024) {
             hc_S = HC_MAX_S;
             hc_wg = n_wg;
@@ -1458,8 +1575,9 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         hp.q_values = qv; hp.targets = tg; hp.priorities = priorities;
         hp.loss_part = loss_part; hp.dbh_part = dbh_part;
         hp.adam_count = adam_count; hp.b1 = cfg->adam_b1; hp.b2 = cfg->adam_b2; hp.adam_consts = adam_consts;
+        hp.stamps = (g_stamp_layer >= 0 && strcmp(g_stamp_name, "head_chain") == 0) ? g_stamps : nullptr;
         const int lds = head_chain_lds_bytes(hid.out_p, P.nha_p, K, x3 ? 3 : 1);
-        const int cols = ceil_div(hid.out_p, 256) <= 1 ? 1 : ceil_div(hid.out_p, 256) <= 2 ? 2 : 4;
+        const int cols = ceil_div(hid.out_p, HC_THREADS) <= 1 ? 1 : ceil_div(hid.out_p, HC_THREADS) <= 2 ? 2 : 4;
         auto launch_hc = [&](auto kern, int slot) -> int {
             static int configured[6] = {0, 0, 0, 0, 0, 0};
             if (lds > 65536 && lds > configured[slot]) {
@@ -1467,7 +1585,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 configured[slot] = lds;
             }
-            hipLaunchKernelGGL(kern, dim3(hc_wg), dim3(256), lds, st, hp);
+            hipLaunchKernelGGL(kern, dim3(hc_wg), dim3(HC_THREADS), lds, st, hp);
             ISDQN_HIP_CHECK(hipGetLastError());
             return ISDQN_OK;
         };
@@ -1480,7 +1598,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         // gradient stream they are enqueued there behind the first fork the backward pass makes anyway (every fork
         // costs the main stream a dependency bubble, so none is spent on these two small kernels alone).
         if (!ss) {
-            hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p,
+            hipLaunchKernelGGL(loss_finalize_kernel, dim3(ceil_div(K, 16) + ceil_div(P.nha_p, 16)), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p,
                                losses, loss_accum, ws + P.dbh_off, (int*)nullptr, cfg->adam_b1, cfg->adam_b2, adam_consts);
             ISDQN_HIP_CHECK(hipGetLastError());
         }
@@ -1489,7 +1607,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                            P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n,
                            learn ? ws + P.dout_off : nullptr, qv, tg, priorities, loss_part, dbh_part);
         ISDQN_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p,
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(ceil_div(K, 16) + ceil_div(P.nha_p, 16)), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p,
                            losses, loss_accum, learn ? ws + P.dbh_off : nullptr, learn ? adam_count : nullptr,
                            cfg->adam_b1, cfg->adam_b2, adam_consts);
         ISDQN_HIP_CHECK(hipGetLastError());
@@ -1516,7 +1634,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     auto run_head_deferred = [&](hipStream_t s2) -> int {
         if (!head_deferred) return ISDQN_OK;
         head_deferred = false;
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s2, loss_part, dbh_part, n_blk, B, K, P.nha_p, losses,
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(ceil_div(K, 16) + ceil_div(P.nha_p, 16)), dim3(256), 0, s2, loss_part, dbh_part, n_blk, B, K, P.nha_p, losses,
                            loss_accum, ws + P.dbh_off, (int*)nullptr, cfg->adam_b1, cfg->adam_b2, adam_consts);
         ISDQN_HIP_CHECK(hipGetLastError());
         MatSrc A{ws + P.dout_off, P.nha_p, B, head.out_p, 1};

@@ -38,6 +38,8 @@ span_cyc = s[:, 5].max() - t0
 span_rt = (s[:, 7].max() - s[:, 7].min())  # start-to-last-start only; use as lower bound
 order = np.argsort(s[:, 0])
 names = ["fill(load+convert+write)", "weights0+sync", "K loop", "epilogue issue", "store drain"]
+if layer == "head_chain":
+    names = ["operand requests + hidden rows -> LDS", "head GEMM", "q reduce + targets/TD", "data-gradient AXPY", "LayerNorm backward"]
 print("(layer may be e.g. Conv_1 for the forward kernel or dgrad:Conv_1 for the data-gradient kernel of that layer)")
 d = np.diff(s[:, :6], axis=1)
 ghz = float(os.environ.get("GHZ", "2.0"))
@@ -47,6 +49,13 @@ print("workgroup start, us after the first (realtime): p10 %.2f p25 %.2f p50 %.2
 print("start histogram (2 us bins):", np.histogram(rt, bins=np.arange(0, rt.max() + 2, 2))[0].tolist())
 for i, n in enumerate(names):
     print(f"{n:28s} median {np.median(d[:, i]):9.0f} cyc  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}   ~{np.median(d[:, i]) / ghz / 1e3:6.2f} us @ {ghz} GHz")
+# first-round workgroups run the code cold (instruction cache), later rounds find it warm
+first = rt < 2.0
+if first.sum() and (~first).sum():
+    for i, n in enumerate(names):
+        print(f"   {n:28s} first-round median {np.median(d[first, i]):9.0f}   later rounds {np.median(d[~first, i]):9.0f}")
+    tot = s[:, 5] - s[:, 0]
+    print(f"   per-WG total: first-round {np.median(tot[first]):.0f}  later rounds {np.median(tot[~first]):.0f}")
 print("per-WG total median", np.median(s[:, 5] - s[:, 0]), "cyc; kernel span", span_cyc, "cyc")
 # first-round vs second-round workgroups
 # optional step-level stamps (diagnostic build only): second row block
