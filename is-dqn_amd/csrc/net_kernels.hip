@@ -30,7 +30,7 @@ __device__ inline double pow_int(double b, int t) {
 // Dense layer tail (dqn.py:96-99): sum the split-K slabs, add the bias, LayerNorm over the row,
 // ReLU.  One workgroup per row; the row is staged in LDS between the two passes.
 __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict__ slabs, int n_slabs,
-                                                         int64_t slab_stride, int rows, int F, int Fp,
+                                                         int64_t slab_stride, int64_t row_pitch, int rows, int F, int Fp,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int has_relu,
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict
                 par[w][e] = *(const ISDQN_GLOBAL float*)((src != nullptr && c + e < F) ? src + c + e : zero_chunk());
         }
         float v0 = 0.f, v1 = 0.f;
-        const float* p = slabs + (int64_t)row * Fp + c;
+        const float* p = slabs + (int64_t)row * row_pitch + c;
         int s = 0;
         for (; s + 16 <= n_slabs; s += 16) {
             float2 t[16];
@@ -402,8 +402,13 @@ __global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, in
 // off the critical path).
 // ---------------------------------------------------------------------------------------------
 struct HeadChainParams {
-    const float* act;   // [2B][Fp] hidden activations: online rows, then next-state rows
-    const float* z;     // [B][Fp]  hidden pre-activations of the online rows
+    // hidden dense layer, finished inside this kernel for the rows a workgroup owns (dense_post_kernel's work)
+    const float* slabs;     // [2B][n_slabs][Fp] split-K partial products of the hidden layer (row-interleaved)
+    int n_slabs;
+    int64_t slab_stride, row_pitch;  // Fp, n_slabs * Fp
+    const float* hbias;     // [F] hidden bias
+    float* act;             // [2B][Fp] post-activation rows (rows [0,B): states, [B,2B): next states), written here
+    float* z;               // [B][Fp]  pre-LayerNorm rows of the states, written here
     const float* W;     // [O][Fp]
     const float* bias;  // [O]
     const float* gamma; // hidden LayerNorm scale / bias, or null
@@ -439,8 +444,8 @@ constexpr int HC_KU = 16 / HC_WAVES;  // K-steps per wave and work item (an item
 __host__ __device__ inline int head_chain_pitch(int Fp) { return (Fp + 31) / 32 * 32 + 8; }
 static inline int head_chain_lds_bytes(int Fp, int Op, int K, int passes) {
     const int PA = head_chain_pitch(Fp);
-    return (passes >= 2 ? 2 : 1) * 16 * PA * 2 + (HC_WAVES * 16 * Op + 16 * Op + HC_MAX_S * Op + Op) * 4 + HC_MAX_S * K * 8 +
-           HC_WAVES * HC_MAX_S * 2 * 4 + 64;
+    return (passes >= 2 ? 2 : 1) * 16 * PA * 2 + (HC_WAVES * 16 * Op + 16 * Op + HC_MAX_S * Op + Op + 4 + 2 * HC_MAX_S * Fp) * 4 + HC_MAX_S * K * 8 +
+           HC_WAVES * 2 * HC_MAX_S * 2 * 4 + 64;
 }
 
 template <int PASSES, int COLS>
@@ -455,8 +460,9 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
     float* s_dq = s_q + 16 * p.Op;                                       // [HC_MAX_S][Op]
     float* s_d = s_dq + HC_MAX_S * p.Op;                                 // [HC_MAX_S][K]
     float* s_td = s_d + HC_MAX_S * p.K;
-    float* s_red = s_td + HC_MAX_S * p.K;                                // [HC_WAVES][HC_MAX_S][2]
-    float* s_bias = s_red + HC_WAVES * HC_MAX_S * 2;                            // [Op]
+    float* s_red = s_td + HC_MAX_S * p.K;                                // [HC_WAVES][2 * HC_MAX_S][2]
+    float* s_bias = s_red + HC_WAVES * 2 * HC_MAX_S * 2;                 // [Op]
+    float* s_pre = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_bias + p.Op) + 15) & ~(uintptr_t)15);  // [2 * HC_MAX_S][Fp] hidden pre-activations, 16-B aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define HC_STAMP(i)                                                                                     \
@@ -475,44 +481,74 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
         p.adam_consts[1] = (float)(1.0 - pow_int((double)p.b2, t));
     }
 
-    // Every global load of this kernel is requested a phase before it is needed, and nothing touches a loaded
-    // register where it is requested: 64 workgroups on 64 CUs run a chain of short phases, the data were last written
-    // from other XCDs (a first touch costs ~4000 cycles), and a phase that starts with its own round trip costs
-    // more than its work.
-    // ---- hidden rows -> LDS (bf16 hi/lo; columns >= Fp zero): two chunks per thread in flight.  Only the 2S rows of
-    //      this workgroup are staged: MFMA output rows depend on their own A row only, and nothing reads the q rows
-    //      of the remaining tile rows, so those LDS rows stay as they are ----
-    const int cpr = (PA - 8) / 8, n_chunks = 2 * S * cpr;
-    float hv[2][8];
-    int hdst[2];
-    auto request_rows = [&](int cb) {
+    // Global loads are requested a phase before they are needed, and nothing touches a loaded register where it is
+    // requested (the data were last written from other XCDs: a first touch costs ~4000 cycles).
+    // ---- operands of the later phases (raw: converted where they are used) ----
+    int act[HC_MAX_S];  // action of the S transitions (selects the head rows the data gradient reads)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int c = cb + u * HC_THREADS + tid;
-            const int row = c / cpr, cc = c - row * cpr;
-            const int smp = row < S ? row : row - S;
-            const bool ok = c < n_chunks && b0 + smp < p.B && cc * 8 < Fp;
-            const int64_t grow = row < S ? (int64_t)(b0 + smp) : (int64_t)p.B + b0 + smp;
-            load8_aligned(ok ? p.act + (grow * Fp + cc * 8) : zero_chunk(), hv[u]);
-            hdst[u] = c < n_chunks ? row * PA + cc * 8 : -1;
-        }
-    };
-    auto stage_rows = [&]() {
+    for (int s = 0; s < HC_MAX_S; ++s) act[s] = *(const ISDQN_GLOBAL int*)((s < S && b0 + s < p.B) ? (const void*)(p.action + b0 + s) : zero_chunk());
+    float td_r;          // reward, terminal flag of this thread's (transition, head) pair
+    uint8_t td_term;
+    {
+        const int s = tid / K;
+        const bool ok = tid < S * K && b0 + s < p.B;
+        td_r = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.reward + b0 + s) : zero_chunk());
+        td_term = *(const ISDQN_GLOBAL uint8_t*)(ok ? (const void*)(p.terminal + b0 + s) : zero_chunk());
+    }
+    const float bias_v = *(const ISDQN_GLOBAL float*)(tid < p.O ? (const void*)(p.bias + tid) : zero_chunk());
+    float ga[COLS], be[COLS];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            bf16x8 hi, lo;
-            if constexpr (PASSES >= 2) {
-                split8(hv[u], hi, lo);
-                if (hdst[u] >= 0) *reinterpret_cast<bf16x8*>(a_lo + hdst[u]) = lo;
-            } else {
-                round8(hv[u], hi);
-            }
-            if (hdst[u] >= 0) *reinterpret_cast<bf16x8*>(a_hi + hdst[u]) = hi;
-        }
-    };
-    request_rows(0);
+    for (int j = 0; j < COLS; ++j) {
+        const int c = tid + j * HC_THREADS;
+        const bool ok = p.gamma != nullptr && c < p.F;
+        ga[j] = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.gamma + c) : zero_chunk());
+        be[j] = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.beta + c) : zero_chunk());
+    }
 
-    // ---- q = a W^T work items, see below; the first batch of W fragments is requested behind the hidden rows ----
+    // ---- the hidden dense layer is finished HERE for the 2S rows of this workgroup (dqn.py:96-99; what
+    //      dense_post_kernel does in the forward-only path): split-K slabs summed in slab order, + bias, LayerNorm, ReLU.
+    //      The rows go to HBM once (act: the head's weight gradient reads the state rows; z: debug / tests), to LDS as
+    //      bf16 hi/lo for the head GEMM, and the pre-LayerNorm values stay in registers for the backward below.
+    //      Tile rows 2S..15 are not staged: MFMA output rows depend on their own A row only, and nothing reads the q
+    //      rows of those tile rows ----
+    constexpr int R2 = 2 * HC_MAX_S;
+    constexpr int TPR = HC_THREADS / R2;  // threads per tile row (two waves): 16-byte loads, one row per thread
+    constexpr int SB = 32;                // slabs per batch = loads in flight per thread
+    static_assert(TPR % 64 == 0, "a wave must not straddle two rows");
+    float m1 = 0.f, m2 = 0.f;  // LayerNorm sums of this thread's row (over its columns)
+    {
+        const int r = tid / TPR, q = tid - r * TPR;
+        const int smp = r < S ? r : r - S;
+        const bool row_ok = r < 2 * S && b0 + smp < p.B;
+        const int64_t grow = r < S ? (int64_t)(b0 + smp) : (int64_t)p.B + b0 + smp;
+        for (int c0 = q * 4; c0 < Fp; c0 += TPR * 4) {  // (one pass up to 512 columns)
+            float hb4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hb4[e] = *(const ISDQN_GLOBAL float*)(c0 + e < p.F ? (const void*)(p.hbias + c0 + e) : zero_chunk());
+            const ISDQN_GLOBAL f32x4* base = (const ISDQN_GLOBAL f32x4*)(row_ok ? (const void*)(p.slabs + grow * p.row_pitch + c0) : zero_chunk());
+            const int64_t strd = row_ok ? p.slab_stride / 4 : 0;  // (Fp is a multiple of 8)
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < p.n_slabs; s0 += SB) {
+                f32x4 t[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) t[u] = base[min(s0 + u, p.n_slabs - 1) * strd];  // tail: clamped, masked in the sum
+#pragma unroll
+                for (int u = 0; u < SB; ++u)
+                    if (s0 + u < p.n_slabs) sum += t[u];  // (uniform condition; slab order)
+            }
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = c0 + e < p.F ? sum[e] + hb4[e] : 0.f;
+                m1 += v[e];
+                m2 += v[e] * v[e];
+            }
+            *reinterpret_cast<float4*>(s_pre + r * Fp + c0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+
+    HC_STAMP(6);  // slab sums of this thread's row done
+    // ---- q = a W^T work items, see below; the first batch of W fragments travels under the LayerNorm ----
     const int nkt = (PA - 8) / 32, NT = (Op + 15) / 16;
     const int nks = (nkt + 15) / 16, n_items = ((NT + 1) / 2) * nks;
     const int kg8 = (lane >> 4) * 8;
@@ -531,40 +567,52 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
     float wv0[2][HC_KU][8], wv1[2][HC_KU][8];
     issue_w(wv0, 0);
 
-    // ---- operands of the later phases (raw: converted where they are used) ----
-    int act[HC_MAX_S];  // action of the S transitions (selects the head rows the data gradient reads)
-#pragma unroll
-    for (int s = 0; s < HC_MAX_S; ++s) act[s] = *(const ISDQN_GLOBAL int*)((s < S && b0 + s < p.B) ? (const void*)(p.action + b0 + s) : zero_chunk());
-    float td_r;          // reward, terminal flag of this thread's (transition, head) pair
-    uint8_t td_term;
+    float zv[HC_MAX_S][COLS];  // pre-LayerNorm values of the state rows (zero outside the row / the transition range)
     {
-        const int s = tid / K;
-        const bool ok = tid < S * K && b0 + s < p.B;
-        td_r = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.reward + b0 + s) : zero_chunk());
-        td_term = *(const ISDQN_GLOBAL uint8_t*)(ok ? (const void*)(p.terminal + b0 + s) : zero_chunk());
-    }
-    const float bias_v = *(const ISDQN_GLOBAL float*)(tid < p.O ? (const void*)(p.bias + tid) : zero_chunk());
-    float zv[HC_MAX_S][COLS], ga[COLS], be[COLS];
-#pragma unroll
-    for (int s = 0; s < HC_MAX_S; ++s)
-#pragma unroll
-        for (int j = 0; j < COLS; ++j) {
-            const int c = tid + j * HC_THREADS;
-            const bool ok = s < S && b0 + s < p.B && c < p.F;
-            zv[s][j] = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.z + (int64_t)(b0 + s) * Fp + c) : zero_chunk());
+        for (int off = 32; off > 0; off >>= 1) {
+            m1 += __shfl_xor(m1, off);
+            m2 += __shfl_xor(m2, off);
         }
+        if (lane == 0) {
+            s_red[wave * 2] = m1;
+            s_red[wave * 2 + 1] = m2;
+        }
+        __syncthreads();  // row sums and the pre-activation rows (s_pre) are visible
+        constexpr int WPR = TPR / 64;  // waves per row
 #pragma unroll
-    for (int j = 0; j < COLS; ++j) {
-        const int c = tid + j * HC_THREADS;
-        const bool ok = p.gamma != nullptr && c < p.F;
-        ga[j] = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.gamma + c) : zero_chunk());
-        be[j] = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.beta + c) : zero_chunk());
-    }
-
-    stage_rows();
-    for (int cb = 2 * HC_THREADS; cb < n_chunks; cb += 2 * HC_THREADS) {  // (2S rows of more than 2048 / (2S) columns)
-        request_rows(cb);
-        stage_rows();
+        for (int r = 0; r < R2; ++r) {
+            float a1 = s_red[r * WPR * 2], a2 = s_red[r * WPR * 2 + 1];
+#pragma unroll
+            for (int w = 1; w < WPR; ++w) {  // fixed order
+                a1 += s_red[(r * WPR + w) * 2];
+                a2 += s_red[(r * WPR + w) * 2 + 1];
+            }
+            const float mean = a1 / (float)p.F;
+            const float rstd = rsqrtf(fmaxf(a2 / (float)p.F - mean * mean, 0.f) + 1e-6f);
+            const int smp = r < S ? r : r - S;
+            const bool row_ok = r < 2 * S && b0 + smp < p.B;
+            const int64_t grow = r < S ? (int64_t)(b0 + smp) : (int64_t)p.B + b0 + smp;
+#pragma unroll
+            for (int j = 0; j < COLS; ++j) {
+                const int c = tid + j * HC_THREADS;
+                const float v = c < Fp ? s_pre[r * Fp + c] : 0.f;
+                float y = v;
+                if (p.gamma != nullptr && c < p.F) y = (v - mean) * (rstd * ga[j]) + be[j];
+                y = fmaxf(y, 0.f);  // (the head chain requires a ReLU hidden layer)
+                if (c >= p.F) y = 0.f;
+                if (row_ok && c < Fp) {
+                    p.act[grow * Fp + c] = y;
+                    if (r < S) p.z[grow * Fp + c] = v;
+                }
+                if (r < 2 * S && c < PA - 8) {
+                    const float ys = row_ok ? y : 0.f;
+                    const __bf16 h = (__bf16)ys;
+                    a_hi[r * PA + c] = h;
+                    if constexpr (PASSES >= 2) a_lo[r * PA + c] = (__bf16)(ys - (float)h);
+                }
+                if (r < HC_MAX_S) zv[r < HC_MAX_S ? r : 0][j] = (row_ok && r < S && c < p.F) ? v : 0.f;
+            }
+        }
     }
     for (int i = tid; i < HC_MAX_S * Op; i += HC_THREADS) s_dq[i] = 0.f;
     if (tid < Op) s_bias[tid] = bias_v;
@@ -1134,8 +1182,9 @@ static int plain_narrow(bool x3, const MatSrc& A, const MatSrc& B, float* C, int
     return launch_plain<128, 64, 2, 2, ATR, BTR, 1, true, false>(A, nullptr, 0, B, C, ldc, M, N, K, splits, slab_stride, st);
 }
 
+// `skip_post`: leave the split-K slabs as they are (the head chain kernel finishes the layer for its own rows)
 static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int rows,
-                     int z_rows, float* slab, float* act, float* z, hipStream_t st) {
+                     int z_rows, float* slab, float* act, float* z, hipStream_t st, bool skip_post = false) {
     MatSrc A, B;
     const float* A2 = nullptr;
     int a_split = 0;
@@ -1146,24 +1195,28 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInpu
         A = MatSrc{act_in, l.in_p, rows, l.in_p, 1};
     }
     B = MatSrc{params + l.w_off, l.in_p, l.out_f, l.in_p, 1};
-    const int64_t slab_stride = (int64_t)rows * l.out_p;
+    // split-K partial products, row-interleaved: slab s of row m at slab[(m * ns + s) * out_p].  The ns partial rows of
+    // one output row are one contiguous block (64 KB at the headline size) for whoever sums them; in [slab][row]
+    // order they sit 1 MB apart, 32 pages per reader.
+    const int ns = effective_splits(l.in_unpadded_ld ? l.in_f : l.K, l.fwd_splits);
+    const int64_t slab_stride = l.out_p;
+    const int ldc = ns * l.out_p;
     int rc;
     if (l.in_unpadded_ld) {
         // caller-provided observations: no alignment promise; MatSrc bounds use the true widths
         MatSrc Bu = B;
         Bu.inner = l.in_f;
-        rc = A2 ? plain_big<false, false, false, true>(x3, A, A2, a_split, Bu, slab, l.out_p, rows, l.out_f, l.in_f,
+        rc = A2 ? plain_big<false, false, false, true>(x3, A, A2, a_split, Bu, slab, ldc, rows, l.out_f, l.in_f,
                                                        l.fwd_splits, slab_stride, st)
-                : plain_big<false, false, false, false>(x3, A, nullptr, 0, Bu, slab, l.out_p, rows, l.out_f, l.in_f,
+                : plain_big<false, false, false, false>(x3, A, nullptr, 0, Bu, slab, ldc, rows, l.out_f, l.in_f,
                                                         l.fwd_splits, slab_stride, st);
     } else {
-        rc = plain_big<false, false>(x3, A, nullptr, 0, B, slab, l.out_p, rows, l.out_f, l.K, l.fwd_splits, slab_stride,
+        rc = plain_big<false, false>(x3, A, nullptr, 0, B, slab, ldc, rows, l.out_f, l.K, l.fwd_splits, slab_stride,
                                      st);
     }
-    if (rc) return rc;
-    int ns = effective_splits(l.in_unpadded_ld ? l.in_f : l.K, l.fwd_splits);
+    if (rc || skip_post) return rc;
     hipLaunchKernelGGL(dense_post_kernel, dim3(rows), dim3(256), 3 * l.out_p * sizeof(float), st, slab, ns, slab_stride,
-                       rows, l.out_f, l.out_p, params + l.b_off, l.has_ln ? params + l.g_off : nullptr,
+                       (int64_t)ldc, rows, l.out_f, l.out_p, params + l.b_off, l.has_ln ? params + l.g_off : nullptr,
                        l.has_ln ? params + l.be_off : nullptr, l.has_relu, act, z, z_rows);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
@@ -1171,7 +1224,7 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInpu
 
 // forward over n_img images; hidden activations -> ws act regions, head output -> q_out [n_img][nha_p]
 static int net_forward(const Plan& P, bool x3, const float* params, const NetInput& in, int n_img, int z_img,
-                       float* ws, float* q_out, hipStream_t st, int n_run = -1) {
+                       float* ws, float* q_out, hipStream_t st, int n_run = -1, int skip_post_layer = -1) {
     const float* prev = nullptr;
     if (n_run < 0) n_run = P.n_layers;
     for (int i = 0; i < n_run; ++i) {
@@ -1182,7 +1235,8 @@ static int net_forward(const Plan& P, bool x3, const float* params, const NetInp
         if (l.kind == 0)
             rc = conv_fwd(l, x3, params, in, prev, n_img, z_img, act, z, st);
         else
-            rc = dense_fwd(l, x3, params, in, prev, n_img, l.is_head ? 0 : z_img, ws + P.slab_off, act, z, st);
+            rc = dense_fwd(l, x3, params, in, prev, n_img, l.is_head ? 0 : z_img, ws + P.slab_off, act, z, st,
+                           i == skip_post_layer);
         if (rc) return rc;
         prev = act;
     }
@@ -1551,7 +1605,8 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     hipStream_t wst = ss ? ss->stream : st;  // stream of the weight gradients
 
     // ---- forward on concat(state, next_state) (isdqn.py:95) ----
-    rc = net_forward(P, x3, params, in, P.N2, B, ws, ws + P.q_off, st, hc_S ? P.n_layers - 1 : -1);
+    rc = net_forward(P, x3, params, in, P.N2, B, ws, ws + P.q_off, st, hc_S ? P.n_layers - 1 : -1,
+                     hc_S ? P.n_layers - 2 : -1);
     if (rc) return rc;
 
     // ---- targets, loss, dL/dq ----
@@ -1564,6 +1619,11 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     if (hc_S) {
         HeadChainParams hp;
         hp.act = ws + hid.act_off; hp.z = ws + hid.z_off;
+        hp.slabs = ws + P.slab_off;
+        hp.n_slabs = effective_splits(hid.in_unpadded_ld ? hid.in_f : hid.K, hid.fwd_splits);
+        hp.slab_stride = hid.out_p;
+        hp.row_pitch = (int64_t)hp.n_slabs * hid.out_p;
+        hp.hbias = params + hid.b_off;
         hp.W = params + head.w_off; hp.bias = params + head.b_off;
         hp.gamma = hid.has_ln ? params + hid.g_off : nullptr;
         hp.beta = hid.has_ln ? params + hid.be_off : nullptr;

@@ -56,6 +56,8 @@ if first.sum() and (~first).sum():
         print(f"   {n:28s} first-round median {np.median(d[first, i]):9.0f}   later rounds {np.median(d[~first, i]):9.0f}")
     tot = s[:, 5] - s[:, 0]
     print(f"   per-WG total: first-round {np.median(tot[first]):.0f}  later rounds {np.median(tot[~first]):.0f}")
+if layer == "head_chain" and s[:, 6].any():
+    print(f"   of the first phase: slab sums + bias until {np.median(s[:, 6] - s[:, 0]):.0f} cyc after kernel start (thread 0)")
 print("per-WG total median", np.median(s[:, 5] - s[:, 0]), "cyc; kernel span", span_cyc, "cyc")
 # first-round vs second-round workgroups
 # optional step-level stamps (diagnostic build only): second row block
