@@ -158,18 +158,30 @@ def test_param_layout_round_trip():
             np.testing.assert_array_equal(got[mod][leaf], params[mod][leaf])
 
 
+FC_SHAPES = [
+    # (feats, K, A, B), adam_eps
+    pytest.param(((100, 100), 1, 4, 32, 1e-8), id="lunar-lander-100x100"),   # BASELINE config 1
+    pytest.param(((64,), 2, 3, 9, 1e-8), id="one-hidden-layer-on-raw-observations"),
+    # hidden width above 512: two column passes and two K-step groups in the head chain kernel; ragged batch.
+    # (Atari epsilon: with 1e-8 any of the 180k parameters whose gradient is at rounding-noise level moves by a full
+    # +-lr per step, and the comparison would measure that amplification, not the kernels)
+    pytest.param(((300, 600), 3, 5, 17, 1.5e-4), id="wide-hidden-600"),
+]
+
+
 @pytest.mark.parametrize("precision", ["bf16x3"])
-def test_fc_architecture_lunar_lander_shape(precision):
-    """BASELINE config 1 shape: fc [100,100], K=1, batch 32, 8-dim observations, 4 actions."""
+@pytest.mark.parametrize("shape", FC_SHAPES)
+def test_fc_architecture_lunar_lander_shape(shape, precision):
+    """fc torso (BASELINE config 1 shape: fc [100,100], K=1, batch 32, 8-dim observations, 4 actions) and variants."""
     from slimdqn._engine import QNetEngine
     from oracle.isdqn import iSDQN as OracleAgent
     from oracle.replay_buffer import ReplayElement
     from tests.gpu_helpers import perturbed_params
 
-    feats, K, A, B, obs = (100, 100), 1, 4, 32, (8,)
+    (feats, K, A, B, eps), obs = shape, (8,)
     params = perturbed_params(0, obs, feats, "fc", (1 + K) * A, True)
-    oracle = OracleAgent(0, obs, A, K, list(feats), True, False, "fc", 3e-4, 0.99, 1, 1, 1, adam_eps=1e-8, params=params)
-    eng = QNetEngine(obs, A, 1 + K, feats, "fc", True, B, gamma_n=0.99, learning_rate=3e-4, adam_eps=1e-8, precision=precision)
+    oracle = OracleAgent(0, obs, A, K, list(feats), True, False, "fc", 3e-4, 0.99, 1, 1, 1, adam_eps=eps, params=params)
+    eng = QNetEngine(obs, A, 1 + K, feats, "fc", True, B, gamma_n=0.99, learning_rate=3e-4, adam_eps=eps, precision=precision)
     eng.import_flax(params)
     rng = np.random.default_rng(0)
     state = rng.normal(size=(B, 8)).astype(np.float32)
