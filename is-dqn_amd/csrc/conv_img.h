@@ -52,6 +52,23 @@ struct ConvImgTraits {
     static constexpr int A_STAGE = A_PLANES * GA::ELEMS;
 };
 
+// Workgroup id -> (image, tile of the image) such that the tiles of one image run on the SAME XCD (hardware places
+// workgroup w on XCD w mod 8): the tiles of an image re-read the same input rows (overlapping frame rows of the first
+// layer, the whole dz image for the stride classes of a data gradient), and on one XCD the second reader finds them in
+// that XCD's L2.  Groups of 8 images: id = group * 8T + t * 8 + xcd  ->  image group * 8 + xcd, tile t.  The tail group
+// (n_img not a multiple of 8) keeps the plain order.
+__device__ __forceinline__ void xcd_image_tile(int wg, int n_img, int T, int& j, int& tile) {
+    const int full = (n_img / 8) * 8 * T;
+    if (T > 1 && wg < full) {
+        const int grp = wg / (8 * T), r = wg - grp * 8 * T;
+        j = grp * 8 + (r & 7);
+        tile = r >> 3;
+    } else {
+        j = wg / T;
+        tile = wg - j * T;
+    }
+}
+
 // Four waves; each owns all MT channel tiles of 32 output pixels.  (An eight-wave variant -- two waves per SIMD sharing
 // the image, channel halves per wave -- was measured slower: barrier-locked waves do not overlap each other.)
 // The uint8 first layer (MT = 2: 2048 workgroups of 38 KB LDS at the headline size) is asked to fit four workgroups per
@@ -77,8 +94,8 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
     }
     ISDQN_STAMP(0);
     constexpr int mt0 = 0;
-    const int j = (int)blockIdx.x / p.tiles_per_img;
-    const int tile = (int)blockIdx.x - j * p.tiles_per_img;
+    int j, tile;
+    xcd_image_tile((int)blockIdx.x, p.n_img, p.tiles_per_img, j, tile);
     const int p0 = tile * 128;
     const int oy_min = p0 / g.wout;
     const int row_base = oy_min * g.stride - g.pad;  // global input row of local row 0
@@ -767,8 +784,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     }
     ISDQN_STAMP(0);
 
-    const int j = (int)blockIdx.x / p.tiles_per_img;
-    int tl = (int)blockIdx.x - j * p.tiles_per_img;
+    int j, tl;
+    xcd_image_tile((int)blockIdx.x, p.n_img, p.tiles_per_img, j, tl);
     int cls = 0;
     while (cls + 1 < p.n_classes && tl >= p.cls_tile_start[cls + 1]) ++cls;
     const int q0 = (tl - p.cls_tile_start[cls]) * 128;  // first class-local pixel of this tile
