@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include "conv_img.h"
 #include "net_plan.h"
 #include "net_problems.h"
@@ -432,9 +433,11 @@ struct HeadChainParams {
     long long* stamps;  // profiling only (isdqn_debug_set_stamps "head_chain"): [workgroup][8] phase boundaries
 };
 
-// HC_MAX_S (net_plan.h): transitions per workgroup.  The kernel is instruction-issue bound (one wave per SIMD, a few
-// thousand instructions executed once), and the target / data-gradient / LayerNorm phases scale with S: two
-// transitions on 128 workgroups beat four on 64 although the head weights are then read twice as often from L2.
+// Transitions per workgroup (template parameter SMAX = 1, 2 or 4; HC_MAX_S in net_plan.h is the largest).  The kernel
+// is instruction-issue bound (a few thousand instructions executed once per wave), and the target / data-gradient /
+// LayerNorm phases scale with S, so few transitions on many workgroups win -- until every one of too many workgroups
+// streams the whole head matrix from L2: S = 1 at B = 256 (20 us; S = 2: 23 us; S = 4 on 256 threads: 22 us before the
+// dense_post fusion), S = 4 at B = 1024 (learn_or_loss picks about 256 workgroups).
 constexpr int HC_MAX_COLS = 4;  // hidden width up to HC_THREADS * 4 (columns per thread: template parameter COLS)
 // Eight waves: the kernel executes a few thousand instructions ONCE per wave, so it is bound by instruction issue and
 // its dependency stalls; two waves per SIMD interleave, and each owns half the K-steps / columns.
@@ -442,13 +445,13 @@ constexpr int HC_THREADS = 512, HC_WAVES = HC_THREADS / 64;
 constexpr int HC_KU = 16 / HC_WAVES;  // K-steps per wave and work item (an item covers 16 K-steps)
 
 __host__ __device__ inline int head_chain_pitch(int Fp) { return (Fp + 31) / 32 * 32 + 8; }
-static inline int head_chain_lds_bytes(int Fp, int Op, int K, int passes) {
+static inline int head_chain_lds_bytes(int Fp, int Op, int K, int passes, int S) {
     const int PA = head_chain_pitch(Fp);
-    return (passes >= 2 ? 2 : 1) * 16 * PA * 2 + (HC_WAVES * 16 * Op + 16 * Op + HC_MAX_S * Op + Op + 4 + 2 * HC_MAX_S * Fp) * 4 + HC_MAX_S * K * 8 +
-           HC_WAVES * 2 * HC_MAX_S * 2 * 4 + 64;
+    return (passes >= 2 ? 2 : 1) * 16 * PA * 2 + (HC_WAVES * 16 * Op + 16 * Op + S * Op + Op + 4 + 2 * S * Fp) * 4 + S * K * 8 +
+           HC_WAVES * 2 * S * 2 * 4 + 64;
 }
 
-template <int PASSES, int COLS>
+template <int PASSES, int COLS, int SMAX>
 __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainParams p) {
     extern __shared__ __attribute__((aligned(16))) char hc_smem[];
     const int PA = head_chain_pitch(p.Fp);
@@ -457,12 +460,12 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
     __bf16* a_lo = a_hi + 16 * PA;
     float* qpart = reinterpret_cast<float*>(a_hi + A_PLANES * 16 * PA);  // [HC_WAVES][16][Op]
     float* s_q = qpart + HC_WAVES * 16 * p.Op;                                  // [16][Op]
-    float* s_dq = s_q + 16 * p.Op;                                       // [HC_MAX_S][Op]
-    float* s_d = s_dq + HC_MAX_S * p.Op;                                 // [HC_MAX_S][K]
-    float* s_td = s_d + HC_MAX_S * p.K;
-    float* s_red = s_td + HC_MAX_S * p.K;                                // [HC_WAVES][2 * HC_MAX_S][2]
-    float* s_bias = s_red + HC_WAVES * 2 * HC_MAX_S * 2;                 // [Op]
-    float* s_pre = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_bias + p.Op) + 15) & ~(uintptr_t)15);  // [2 * HC_MAX_S][Fp] hidden pre-activations, 16-B aligned
+    float* s_dq = s_q + 16 * p.Op;                                       // [SMAX][Op]
+    float* s_d = s_dq + SMAX * p.Op;                                 // [SMAX][K]
+    float* s_td = s_d + SMAX * p.K;
+    float* s_red = s_td + SMAX * p.K;                                // [HC_WAVES][2 * SMAX][2]
+    float* s_bias = s_red + HC_WAVES * 2 * SMAX * 2;                 // [Op]
+    float* s_pre = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_bias + p.Op) + 15) & ~(uintptr_t)15);  // [2 * SMAX][Fp] hidden pre-activations, 16-B aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define HC_STAMP(i)                                                                                     \
@@ -484,9 +487,9 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
     // Global loads are requested a phase before they are needed, and nothing touches a loaded register where it is
     // requested (the data were last written from other XCDs: a first touch costs ~4000 cycles).
     // ---- operands of the later phases (raw: converted where they are used) ----
-    int act[HC_MAX_S];  // action of the S transitions (selects the head rows the data gradient reads)
+    int act[SMAX];  // action of the S transitions (selects the head rows the data gradient reads)
 #pragma unroll
-    for (int s = 0; s < HC_MAX_S; ++s) act[s] = *(const ISDQN_GLOBAL int*)((s < S && b0 + s < p.B) ? (const void*)(p.action + b0 + s) : zero_chunk());
+    for (int s = 0; s < SMAX; ++s) act[s] = *(const ISDQN_GLOBAL int*)((s < S && b0 + s < p.B) ? (const void*)(p.action + b0 + s) : zero_chunk());
     float td_r;          // reward, terminal flag of this thread's (transition, head) pair
     uint8_t td_term;
     {
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
     //      bf16 hi/lo for the head GEMM, and the pre-LayerNorm values stay in registers for the backward below.
     //      Tile rows 2S..15 are not staged: MFMA output rows depend on their own A row only, and nothing reads the q
     //      rows of those tile rows ----
-    constexpr int R2 = 2 * HC_MAX_S;
+    constexpr int R2 = 2 * SMAX;
     constexpr int TPR = HC_THREADS / R2;  // threads per tile row (two waves): 16-byte loads, one row per thread
     constexpr int SB = 32;                // slabs per batch = loads in flight per thread
     static_assert(TPR % 64 == 0, "a wave must not straddle two rows");
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
     float wv0[2][HC_KU][8], wv1[2][HC_KU][8];
     issue_w(wv0, 0);
 
-    float zv[HC_MAX_S][COLS];  // pre-LayerNorm values of the state rows (zero outside the row / the transition range)
+    float zv[SMAX][COLS];  // pre-LayerNorm values of the state rows (zero outside the row / the transition range)
     {
         for (int off = 32; off > 0; off >>= 1) {
             m1 += __shfl_xor(m1, off);
@@ -610,11 +613,11 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
                     a_hi[r * PA + c] = h;
                     if constexpr (PASSES >= 2) a_lo[r * PA + c] = (__bf16)(ys - (float)h);
                 }
-                if (r < HC_MAX_S) zv[r < HC_MAX_S ? r : 0][j] = (row_ok && r < S && c < p.F) ? v : 0.f;
+                if (r < SMAX) zv[r < SMAX ? r : 0][j] = (row_ok && r < S && c < p.F) ? v : 0.f;
             }
         }
     }
-    for (int i = tid; i < HC_MAX_S * Op; i += HC_THREADS) s_dq[i] = 0.f;
+    for (int i = tid; i < SMAX * Op; i += HC_THREADS) s_dq[i] = 0.f;
     if (tid < Op) s_bias[tid] = bias_v;
     for (int o = tid + HC_THREADS; o < Op; o += HC_THREADS) s_bias[o] = o < p.O ? p.bias[o] : 0.f;  // (more outputs than threads)
     __syncthreads();  // hidden rows staged
@@ -678,9 +681,9 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
 
     // ---- data-gradient rows: head row (1 + k) * A + action of every (transition, head), four heads per batch; the
     //      first batch is requested here and travels under the target / TD phase ----
-    auto issue_rows = [&](float (&w)[HC_MAX_S][4][COLS], int k0) {
+    auto issue_rows = [&](float (&w)[SMAX][4][COLS], int k0) {
 #pragma unroll
-        for (int s = 0; s < HC_MAX_S; ++s)
+        for (int s = 0; s < SMAX; ++s)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool on = s < S && k0 + u < K;
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
             }
     };
     HC_STAMP(2);  // head GEMM done (this wave)
-    float wr0[HC_MAX_S][4][COLS], wr1[HC_MAX_S][4][COLS];
+    float wr0[SMAX][4][COLS], wr1[SMAX][4][COLS];
     issue_rows(wr0, 0);
     __syncthreads();
     for (int i = tid; i < 2 * S * Op; i += HC_THREADS) {  // (tile rows 2S..15 are nobody's)
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
         if (b < p.B) {
             a = act[0];
 #pragma unroll
-            for (int i = 1; i < HC_MAX_S; ++i) a = s == i ? act[i] : a;
+            for (int i = 1; i < SMAX; ++i) a = s == i ? act[i] : a;
             const float qv = s_q[s * Op + (1 + k) * A + a];
             const float* nq = s_q + (S + s) * Op + k * A;
             float mx = nq[0];
@@ -755,14 +758,14 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
     HC_STAMP(3);  // targets / TD / small stores issued
     // ---- da = dL/dq W (K row-AXPYs per transition, heads in ascending order), then the LayerNorm/ReLU backward of
     //      the hidden row ----
-    float da[HC_MAX_S][COLS];
+    float da[SMAX][COLS];
 #pragma unroll
-    for (int s = 0; s < HC_MAX_S; ++s)
+    for (int s = 0; s < SMAX; ++s)
 #pragma unroll
         for (int j = 0; j < COLS; ++j) da[s][j] = 0.f;
-    auto axpy_rows = [&](const float (&w)[HC_MAX_S][4][COLS], int k0) {
+    auto axpy_rows = [&](const float (&w)[SMAX][4][COLS], int k0) {
 #pragma unroll
-        for (int s = 0; s < HC_MAX_S; ++s)
+        for (int s = 0; s < SMAX; ++s)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool on = s < S && k0 + u < K;
@@ -783,10 +786,10 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
     for (int j = 0; j < COLS; ++j) dg[j] = db[j] = dbias[j] = 0.f;
     if (p.gamma != nullptr) {
         const float inv_c = 1.f / (float)p.F;
-        float r1[HC_MAX_S], r2[HC_MAX_S];
+        float r1[SMAX], r2[SMAX];
         auto block_sum2 = [&]() {  // r1[s], r2[s] summed over the workgroup
 #pragma unroll
-            for (int s = 0; s < HC_MAX_S; ++s)
+            for (int s = 0; s < SMAX; ++s)
                 for (int off = 32; off > 0; off >>= 1) {
                     r1[s] += __shfl_xor(r1[s], off);
                     r2[s] += __shfl_xor(r2[s], off);
@@ -794,25 +797,25 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
             __syncthreads();
             if (lane == 0) {
 #pragma unroll
-                for (int s = 0; s < HC_MAX_S; ++s) {
-                    s_red[(wave * HC_MAX_S + s) * 2] = r1[s];
-                    s_red[(wave * HC_MAX_S + s) * 2 + 1] = r2[s];
+                for (int s = 0; s < SMAX; ++s) {
+                    s_red[(wave * SMAX + s) * 2] = r1[s];
+                    s_red[(wave * SMAX + s) * 2 + 1] = r2[s];
                 }
             }
             __syncthreads();
 #pragma unroll
-            for (int s = 0; s < HC_MAX_S; ++s) {
+            for (int s = 0; s < SMAX; ++s) {
                 r1[s] = s_red[s * 2];
                 r2[s] = s_red[s * 2 + 1];
 #pragma unroll
                 for (int w = 1; w < HC_WAVES; ++w) {  // fixed order
-                    r1[s] += s_red[(w * HC_MAX_S + s) * 2];
-                    r2[s] += s_red[(w * HC_MAX_S + s) * 2 + 1];
+                    r1[s] += s_red[(w * SMAX + s) * 2];
+                    r2[s] += s_red[(w * SMAX + s) * 2 + 1];
                 }
             }
         };
 #pragma unroll
-        for (int s = 0; s < HC_MAX_S; ++s) {
+        for (int s = 0; s < SMAX; ++s) {
             r1[s] = r2[s] = 0.f;
 #pragma unroll
             for (int j = 0; j < COLS; ++j) {  // zv is zero outside the row / the transition range
@@ -821,9 +824,9 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
             }
         }
         block_sum2();
-        float mean[HC_MAX_S], rstd[HC_MAX_S];
+        float mean[SMAX], rstd[SMAX];
 #pragma unroll
-        for (int s = 0; s < HC_MAX_S; ++s) {
+        for (int s = 0; s < SMAX; ++s) {
             mean[s] = r1[s] * inv_c;
             rstd[s] = rsqrtf(fmaxf(r2[s] * inv_c - mean[s] * mean[s], 0.f) + 1e-6f);
             r1[s] = r2[s] = 0.f;
@@ -845,7 +848,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
         }
         block_sum2();
 #pragma unroll
-        for (int s = 0; s < HC_MAX_S; ++s) {
+        for (int s = 0; s < SMAX; ++s) {
             const float m1 = r1[s] * inv_c, m2 = r2[s] * inv_c;
             if (s < S && b0 + s < p.B) {
 #pragma unroll
@@ -861,7 +864,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < HC_MAX_S; ++s) {
+        for (int s = 0; s < SMAX; ++s) {
             if (s < S && b0 + s < p.B) {
 #pragma unroll
                 for (int j = 0; j < COLS; ++j) {
@@ -1594,10 +1597,13 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     static const bool hc_disabled = getenv("ISDQN_NO_HEAD_CHAIN") != nullptr;
     if (learn && !hc_disabled && P.n_layers >= 2 && hid.kind == 1 && !hid.is_head && hid.has_relu &&
         hid.out_p <= HC_THREADS * HC_MAX_COLS && hid.out_p % 8 == 0) {
-        const int n_wg = ceil_div(B, HC_MAX_S);
-        if (n_wg <= hid.part_rows && HC_MAX_S * K <= HC_THREADS &&
-            head_chain_lds_bytes(hid.out_p, P.nha_p, K, x3 ? 3 : 1) <= 150 * 1024) {
-            hc_S = HC_MAX_S;
+        // transitions per workgroup: the per-transition phases scale with S (the kernel is instruction-issue bound) while
+        // every workgroup streams the whole head matrix from L2, so S follows the batch: about 256 workgroups
+        const int S = B >= 1024 ? 4 : B >= 512 ? 2 : 1;
+        const int n_wg = ceil_div(B, S);
+        if (n_wg <= hid.part_rows && S * K <= HC_THREADS &&
+            head_chain_lds_bytes(hid.out_p, P.nha_p, K, x3 ? 3 : 1, S) <= 150 * 1024) {
+            hc_S = S;
             hc_wg = n_wg;
         }
     }
@@ -1636,10 +1642,10 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         hp.loss_part = loss_part; hp.dbh_part = dbh_part;
         hp.adam_count = adam_count; hp.b1 = cfg->adam_b1; hp.b2 = cfg->adam_b2; hp.adam_consts = adam_consts;
         hp.stamps = (g_stamp_layer >= 0 && strcmp(g_stamp_name, "head_chain") == 0) ? g_stamps : nullptr;
-        const int lds = head_chain_lds_bytes(hid.out_p, P.nha_p, K, x3 ? 3 : 1);
+        const int lds = head_chain_lds_bytes(hid.out_p, P.nha_p, K, x3 ? 3 : 1, hc_S);
         const int cols = ceil_div(hid.out_p, HC_THREADS) <= 1 ? 1 : ceil_div(hid.out_p, HC_THREADS) <= 2 ? 2 : 4;
         auto launch_hc = [&](auto kern, int slot) -> int {
-            static int configured[6] = {0, 0, 0, 0, 0, 0};
+            static int configured[18] = {0};
             if (lds > 65536 && lds > configured[slot]) {
                 ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1649,10 +1655,17 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
             ISDQN_HIP_CHECK(hipGetLastError());
             return ISDQN_OK;
         };
-        if (x3) rc = cols == 1 ? launch_hc(&head_chain_kernel<3, 1>, 0) : cols == 2 ? launch_hc(&head_chain_kernel<3, 2>, 1)
-                                                                                     : launch_hc(&head_chain_kernel<3, 4>, 2);
-        else rc = cols == 1 ? launch_hc(&head_chain_kernel<1, 1>, 3) : cols == 2 ? launch_hc(&head_chain_kernel<1, 2>, 4)
-                                                                                  : launch_hc(&head_chain_kernel<1, 4>, 5);
+        auto by_cols = [&](auto passes_c, auto s_c, int base) -> int {
+            constexpr int PS = decltype(passes_c)::value, SS = decltype(s_c)::value;
+            return cols == 1 ? launch_hc(&head_chain_kernel<PS, 1, SS>, base) : cols == 2 ? launch_hc(&head_chain_kernel<PS, 2, SS>, base + 1)
+                                                                            : launch_hc(&head_chain_kernel<PS, 4, SS>, base + 2);
+        };
+        auto by_s = [&](auto passes_c, int base) -> int {
+            return hc_S == 1 ? by_cols(passes_c, std::integral_constant<int, 1>{}, base)
+                 : hc_S == 2 ? by_cols(passes_c, std::integral_constant<int, 2>{}, base + 3)
+                             : by_cols(passes_c, std::integral_constant<int, 4>{}, base + 6);
+        };
+        rc = x3 ? by_s(std::integral_constant<int, 3>{}, 0) : by_s(std::integral_constant<int, 1>{}, 9);
         if (rc) return rc;
         // The loss / head-bias reductions and the head's weight gradient leave the critical path: with a weight-
         // gradient stream they are enqueued there behind the first fork the backward pass makes anyway (every fork

@@ -14,7 +14,7 @@ namespace isdqn {
 
 constexpr int MAX_LAYERS = 12;
 constexpr int LN_MAX_BLOCKS = 256;  // partial-sum slabs of the LayerNorm backward
-constexpr int HC_MAX_S = 2;         // head chain kernel: transitions per workgroup (online + next rows share one 16-row MFMA tile)
+constexpr int HC_MAX_S = 4;         // head chain kernel: most transitions per workgroup (1, 2 or 4 by batch size; online + next rows share one 16-row MFMA tile)
 
 struct Layer {
     int kind;  // 0 conv, 1 dense
@@ -198,7 +198,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
             l.z_off = region(std::string("z/") + l.name, (int64_t)P.B * l.out_elems_p);
             l.dz_off = region(std::string("dz/") + l.name, (int64_t)P.B * l.out_elems_p);
             l.part_rows = LN_MAX_BLOCKS;
-            if (l.kind == 1 && ceil_div(P.B, HC_MAX_S) > l.part_rows) l.part_rows = ceil_div(P.B, HC_MAX_S);  // head chain: one row per workgroup
+            if (l.kind == 1 && P.B > l.part_rows) l.part_rows = P.B;  // head chain: one row per workgroup, as few as one transition each
             l.part_off = -2;  // sized below, once the consumer layer's tiling is known
             l.red_off = region(std::string("red/") + l.name, 3 * (int64_t)l.out_p);
         }
@@ -269,7 +269,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
     P.tg_off = region("targets", (int64_t)P.B * (P.n_heads - 1));
     P.dbh_off = region("dbh", P.nha_p);
     P.adam_tab_off = region("adam_consts", 64);
-    P.lpart_off = region("loss_partials", (int64_t)ceil_div(P.B, HC_MAX_S) * (P.n_heads - 1 + P.nha_p));
+    P.lpart_off = region("loss_partials", (int64_t)P.B * (P.n_heads - 1 + P.nha_p));
     P.ws_bytes = off * 4;
     return ISDQN_OK;
 }
