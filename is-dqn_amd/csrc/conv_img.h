@@ -73,20 +73,27 @@ __device__ __forceinline__ void xcd_image_tile(int wg, int n_img, int T, int& j,
 // the image, channel halves per wave -- was measured slower: barrier-locked waves do not overlap each other.)
 // The uint8 first layer (MT = 2: 2048 workgroups of 38 KB LDS at the headline size) is asked to fit four workgroups per
 // CU (<= 128 registers): at three, its 8 workgroups per CU run as 3 + 3 + 2.
-template <int MT, int PASSES, bool U8>
-__global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 1) void conv_fwd_img_kernel(const ConvImgParams p) {
+// KG = 2 (layers whose image leaves room for one workgroup per CU only): eight waves, two groups of four.  Both groups
+// own the same 128 pixels x all channels and split the K steps (group g takes loop positions g, g+2, ...), each with
+// its own pair of weight stages; group 1's accumulators are added to group 0's through LDS before the epilogue.  Two
+// waves per SIMD interleave where one left every stall exposed (fill, K loop), and -- unlike splitting channels or
+// pixels between eight waves -- the LDS reads per MFMA stay the same.
+template <int MT, int PASSES, bool U8, int KG = 1>
+__global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ? 4 : 1) void conv_fwd_img_kernel(const ConvImgParams p) {
     using T = ConvImgTraits<MT, PASSES, U8>;
     using GA = typename T::GA;
     constexpr int NT = 2;
-    constexpr int NTHR = GEMM_THREADS;
+    constexpr int NTHR = GEMM_THREADS;            // threads of one K group (weight staging, fragments, epilogue)
+    constexpr int NTHR_ALL = GEMM_THREADS * KG;   // all threads (image fill)
     constexpr int MTW = MT;  // channel tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
-    __bf16* a_stage = smem;                              // 2 stages of weight K-slices
-    __bf16* img = smem + 2 * T::A_STAGE;                 // B_PLANES planes of the input tile
+    const int tid_all = threadIdx.x, kg = KG > 1 ? tid_all / GEMM_THREADS : 0;
+    __bf16* a_stage = smem + kg * 2 * T::A_STAGE;        // 2 stages of weight K-slices (per K group)
+    __bf16* img = smem + KG * 2 * T::A_STAGE;            // B_PLANES planes of the input tile
     const ConvGeom& g = p.g;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = tid_all - kg * GEMM_THREADS, lane = tid & 63, wave = tid >> 6;  // (group-local)
 #define ISDQN_STAMP(i)                                                                               \
     if (p.stamps != nullptr && threadIdx.x == 0) {                                                  \
         p.stamps[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime();           \
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
     {
         const int which = tid >> 6, ch = tid & 63;
         const float* src = which == 0 ? p.bias : which == 1 ? p.gamma : p.beta;
-        const bool ok = tid < 192 && ch < g.cout_p && src != nullptr;
+        const bool ok = kg == 0 && tid < 192 && ch < g.cout_p && src != nullptr;
         par_v = *(const ISDQN_GLOBAL float*)(ok ? src + ch : zero_chunk());
     }
 
@@ -153,11 +160,12 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
         }
     };
 
-    const int nsteps_p = (nsteps + PF - 1) / PF * PF;
+    const int nsteps_p = ((nsteps + KG - 1) / KG + PF - 1) / PF * PF;  // loop positions of one K group
     const int rot = (p.ablate & 16) ? 0 : (int)((blockIdx.x >> 3) % (unsigned)nsteps);
-    auto slice = [&](int s) {  // K step handled at loop position s; positions past nsteps read zeros
-        const int k = s + rot;
-        return s < nsteps ? (k >= nsteps ? k - nsteps : k) : nsteps_p;
+    auto slice = [&](int s) {  // K step handled at this group's loop position s; positions past nsteps read zeros
+        const int gs = s * KG + kg;
+        const int k = gs + rot;
+        return gs < nsteps ? (k >= nsteps ? k - nsteps : k) : nsteps_p * KG;
     };
     // the first PF weight slices are requested BEFORE the image fill: they travel under it
 #pragma unroll
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
     // ---------------- stage the input rows of this tile into LDS (zero border included) ----------------
     // FILL_BATCH chunk loads are issued back to back before the first one is consumed: a plain
     // load -> convert -> store loop is one L2/HBM round trip per iteration.
-    constexpr int FILL_BATCH = U8 ? 8 : 12;  // chunks in flight per thread: the 21x21x32 image (10.6 chunks) in ONE round trip
+    constexpr int FILL_BATCH = (U8 ? 8 : 12) / KG;  // chunks in flight per thread: the 21x21x32 image (10.6 chunks) in ONE round trip
     if (p.ablate & 1) {
     } else if constexpr (U8) {
         // planar: img[c][lr][Wp], chunk = 8 consecutive padded columns
@@ -176,12 +184,12 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c < p.fs.stack) fid[c] = p.fs.frame_id(j, c);
-        for (int cb = 0; cb < n_chunks; cb += NTHR * FILL_BATCH) {
+        for (int cb = 0; cb < n_chunks; cb += NTHR_ALL * FILL_BATCH) {
             unsigned long long raw[FILL_BATCH];
             int sh[FILL_BATCH], dst[FILL_BATCH];
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {  // loads only: nothing here touches the loaded registers
-                const int c0 = cb + u * NTHR + tid;
+                const int c0 = cb + u * NTHR_ALL + tid_all;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
                 uint32_t cx, rest, lr, c;
@@ -205,12 +213,12 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
         // channel-last: img[lr][xp][cin_p], chunk = 8 channels of one padded pixel
         const int cpp = g.cin_p / 8;
         const int n_chunks = p.R * p.Wp * cpp;
-        for (int cb = 0; cb < n_chunks; cb += NTHR * FILL_BATCH) {
+        for (int cb = 0; cb < n_chunks; cb += NTHR_ALL * FILL_BATCH) {
             float v[FILL_BATCH][8];
             int dst[FILL_BATCH];
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
-                const int c0 = cb + u * NTHR + tid;
+                const int c0 = cb + u * NTHR_ALL + tid_all;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
                 uint32_t cc, pix, xp, lr;
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
     // own starting slice; workgroups b, b+8, b+16, ... share an XCD, hence the rotation by b/8.
     static_assert(PF % 2 == 0 && PF >= 4, "the fragment sets alternate with the step parity; steps 0..3 are pre-fetched");
     Frags fr[2];
-    if (tid < 192) s_par[tid >> 6][tid & 63] = par_v;
+    if (kg == 0 && tid < 192) s_par[tid >> 6][tid & 63] = par_v;
     stash(0, 0);  // steps 0 and 1 fill the two LDS stages; their ring slots take steps PF and PF+1
     stash(1, 1);
     fetch(0, slice(PF) * GEMM_BK);
@@ -373,6 +381,28 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
             acc[mt][nt] = accs[0][mt][nt];
             if constexpr (NACC == 2) acc[mt][nt] += accs[1][mt][nt];
         }
+    if constexpr (KG > 1) {
+        // The two groups hold partial sums of the same tile.  Group g finalizes pixel tile nt = g of every wave: each
+        // wave hands the OTHER tile to its partner through LDS (the image is dead: the K loop ended with a barrier).
+        static_assert(KG == 2 && NT == 2, "one pixel tile per K group");
+        float* red = reinterpret_cast<float*>(img);  // [group][wave][mt][r][lane]: conflict-free, 4 KB per wave
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float give = kg == 0 ? acc[mt][1][r] : acc[mt][0][r];
+                red[(((kg * 4 + wave) * MTW + mt) * 4 + r) * 64 + lane] = give;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float got = red[((((1 - kg) * 4 + wave) * MTW + mt) * 4 + r) * 64 + lane];
+                if (kg == 0) acc[mt][0][r] += got;
+                else acc[mt][1][r] += got;
+            }
+    }
     if (p.ablate & 4) {
         if (acc[0][0][0] == 12345.678f) p.act[0] = 1.f;  // keep the accumulators alive
         return;
@@ -395,6 +425,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         s1[nt] = s2[nt] = 0.f;
+        if (KG > 1 && nt != kg) continue;  // the partner group finalizes this tile
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -412,6 +443,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+        if (KG > 1 && nt != kg) continue;
         const int pp = p0 + wave * 32 + nt * 16 + (lane & 15);
         float mean = 0.f, rstd = 1.f;
         if (p.gamma != nullptr) {
@@ -447,17 +479,17 @@ __global__ __launch_bounds__(GEMM_THREADS, (U8 && MT == 2 && PASSES == 2) ? 4 : 
 #undef ISDQN_STAMP
 }
 
-template <int MT, int PASSES, bool U8>
+template <int MT, int PASSES, bool U8, int KG = 1>
 static int launch_conv_fwd_img(const ConvImgParams& p, hipStream_t st) {
     using T = ConvImgTraits<MT, PASSES, U8>;
-    const int lds = (2 * T::A_STAGE + T::B_PLANES * p.plane_elems) * 2;
+    const int lds = (KG * 2 * T::A_STAGE + T::B_PLANES * p.plane_elems) * 2;
     static int configured_for = 0;
     if (lds > 65536 && lds > configured_for) {
-        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_img_kernel<MT, PASSES, U8>),
+        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_img_kernel<MT, PASSES, U8, KG>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured_for = lds;
     }
-    hipLaunchKernelGGL((conv_fwd_img_kernel<MT, PASSES, U8>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS), lds,
+    hipLaunchKernelGGL((conv_fwd_img_kernel<MT, PASSES, U8, KG>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS * KG), lds,
                        st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;

@@ -1119,8 +1119,16 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
         if (passes == 2) return mt == 2 ? launch_conv_fwd_img<2, 2, true>(ip, st) : launch_conv_fwd_img<4, 2, true>(ip, st);
         return mt == 2 ? launch_conv_fwd_img<2, 1, true>(ip, st) : launch_conv_fwd_img<4, 1, true>(ip, st);
     }
-    if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false>(ip, st) : launch_conv_fwd_img<4, 3, false>(ip, st);
-    return mt == 2 ? launch_conv_fwd_img<2, 1, false>(ip, st) : launch_conv_fwd_img<4, 1, false>(ip, st);
+    // An image that leaves room for one workgroup per CU only (more than half of the 160 KB) runs with two K groups of
+    // four waves, if the second pair of weight stages still fits and the accumulator exchange fits the image area.
+    const int stage_bytes = (passes >= 2 ? 2 : 1) * (mt * 16) * 48 * 2 * 2;  // two stages of one K group
+    static const bool no_kg = getenv("ISDQN_NO_KGROUPS") != nullptr;
+    const bool kg2 = !no_kg && mt == 4 && lds > 80 * 1024 && lds + stage_bytes <= 150 * 1024 &&
+                     mt * 16 * 128 * 4 <= lds - stage_bytes && l.K >= 8 * GEMM_BK;
+    if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false>(ip, st)
+                          : kg2 ? launch_conv_fwd_img<4, 3, false, 2>(ip, st) : launch_conv_fwd_img<4, 3, false>(ip, st);
+    return mt == 2 ? launch_conv_fwd_img<2, 1, false>(ip, st)
+         : kg2 ? launch_conv_fwd_img<4, 1, false, 2>(ip, st) : launch_conv_fwd_img<4, 1, false>(ip, st);
 }
 
 static int conv_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int n_img,
