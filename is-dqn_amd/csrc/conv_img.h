@@ -539,7 +539,7 @@ struct ConvWgradImgParams {
     FastDiv d_chunk, d_Wp, d_R, d_dzchunk;  // fill index math (see ConvImgParams)
 };
 
-template <bool U8, int PASSES>
+template <bool U8, int PASSES, int NTHR = GEMM_THREADS>
 __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, const ConvGeom& g, const FrameSrc& fs,
                                                  const float* in, int j, int row_base, int R, int Wp, int tid,
                                                  const FastDiv& d_chunk, const FastDiv& d_Wp, const FastDiv& d_R) {
@@ -551,12 +551,12 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c < fs.stack) fid[c] = fs.frame_id(j, c);
-        for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
+        for (int cb = 0; cb < n_chunks; cb += NTHR * FILL_BATCH) {
             unsigned long long raw[FILL_BATCH];
             int sh[FILL_BATCH], dst[FILL_BATCH];
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {  // loads only: nothing here touches the loaded registers
-                const int c0 = cb + u * GEMM_THREADS + tid;
+                const int c0 = cb + u * NTHR + tid;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
                 uint32_t cx, rest, lr, c;
@@ -578,12 +578,12 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
     } else {
         const int cpp = g.cin_p / 8;
         const int n_chunks = R * Wp * cpp;
-        for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
+        for (int cb = 0; cb < n_chunks; cb += NTHR * FILL_BATCH) {
             float v[FILL_BATCH][8];
             int dst[FILL_BATCH];
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
-                const int c0 = cb + u * GEMM_THREADS + tid;
+                const int c0 = cb + u * NTHR + tid;
                 const bool on = c0 < n_chunks;
                 const int cq = on ? c0 : 0;
                 uint32_t cc, pix, xp, lr;
@@ -617,8 +617,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* a0, const __bf16* a1) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int MT, int NTW, int PASSES, bool U8>
-__global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const ConvWgradImgParams p) {
+// WV waves (4 or 8): a column tile is owned by exactly one wave, so eight waves only re-deal the tiles (NTW is per
+// wave; tiles past the last column are computed on column 0 and never stored).  The kernel stages two images per
+// workgroup and runs 4 K steps on each: with one wave per SIMD the two fills are most of its time.
+template <int MT, int NTW, int PASSES, bool U8, int WV = 4>
+__global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgradImgParams p) {
+    constexpr int NTHR = 64 * WV;
     constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
     constexpr int B_PLANES = (PASSES >= 3) ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -630,11 +634,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const Conv
     const int j0 = ig * p.G, j1 = min(p.n_img, j0 + p.G);
     const int grp = lane >> 4, li = lane & 15, q = li >> 2, pq = li & 3;
 
-    // column tiles of this wave: global k' column of tile t = cg*NC + (wave + 4*t)*16
+    // column tiles of this wave: global k' column of tile t = cg*NC + (wave + WV*t)*16
     int col_off[NTW];  // element offset inside the input image contributed by the tile's tap / channel / lane part
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        const int c0 = cg * p.NC + (wave + 4 * t) * 16;
+        const int c0 = cg * p.NC + (wave + WV * t) * 16;  // (>= K for surplus tiles of an uneven deal)
         if constexpr (U8) {
             const int c = c0 >> 6, ky0 = (c0 >> 3) & 7;  // the 16 columns are (ky0, kx 0..7), (ky0+1, kx 0..7)
             col_off[t] = (c * p.R + ky0 + (pq >> 1)) * p.Wp + 4 * (pq & 1);
@@ -660,12 +664,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const Conv
             constexpr int FILL_BATCH = 8;
             const int cpr = g.cout_p / 8;
             const int n_chunks = p.npix_pad * cpr;
-            for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
+            for (int cb = 0; cb < n_chunks; cb += NTHR * FILL_BATCH) {
                 float v[FILL_BATCH][8];
                 int dst[FILL_BATCH];
 #pragma unroll
                 for (int u = 0; u < FILL_BATCH; ++u) {
-                    const int c0 = cb + u * GEMM_THREADS + tid;
+                    const int c0 = cb + u * NTHR + tid;
                     const bool on = c0 < n_chunks;
                     const int cq = on ? c0 : 0;
                     uint32_t cc, pix;
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const Conv
                 }
             }
         }
-        fill_input_image<U8, PASSES>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, tid, p.d_chunk, p.d_Wp, p.d_R);
+        fill_input_image<U8, PASSES, NTHR>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, tid, p.d_chunk, p.d_Wp, p.d_R);
         __syncthreads();
 
         for (int ks = 0; ks < nsteps; ++ks) {
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const Conv
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            const int col = cg * p.NC + (wave + 4 * t) * 16 + li;
+            const int col = cg * p.NC + (wave + WV * t) * 16 + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = mt * 16 + grp * 4 + r;
@@ -743,19 +747,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_wgrad_img_kernel(const Conv
         }
 }
 
-template <int MT, int NTW, int PASSES, bool U8>
+template <int MT, int NTW, int PASSES, bool U8, int WV = 4>
 static int launch_conv_wgrad_img(const ConvWgradImgParams& p, int n_img_groups, hipStream_t st) {
     constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
     constexpr int B_PLANES = (PASSES >= 3) ? 2 : 1;
     const int lds = (A_PLANES * p.dz_plane + B_PLANES * p.in_plane) * 2;
     static int configured_for = 0;
     if (lds > 65536 && lds > configured_for) {
-        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_img_kernel<MT, NTW, PASSES, U8>),
+        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured_for = lds;
     }
-    hipLaunchKernelGGL((conv_wgrad_img_kernel<MT, NTW, PASSES, U8>), dim3(n_img_groups * p.n_col_groups),
-                       dim3(GEMM_THREADS), lds, st, p);
+    hipLaunchKernelGGL((conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>), dim3(n_img_groups * p.n_col_groups),
+                       dim3(64 * WV), lds, st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
 }

@@ -1355,6 +1355,7 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
     const int groups = ceil_div(n_img, l.wgi_G);
     *slabs_out = groups;
 #define WGI(MT_, NTW_, P_, U_) return launch_conv_wgrad_img<MT_, NTW_, P_, U_>(wp, groups, st)
+#define WGI8(MT_, NTW_, P_, U_) return launch_conv_wgrad_img<MT_, NTW_, P_, U_, 8>(wp, groups, st)
     if (l.is_u8) {
         if (mt == 2) { if (l.wgi_ntw == 4) { if (passes == 2) WGI(2, 4, 2, true); else WGI(2, 4, 1, true); }
                        if (l.wgi_ntw == 2) { if (passes == 2) WGI(2, 2, 2, true); else WGI(2, 2, 1, true); } }
@@ -1364,13 +1365,18 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
         if (mt == 2) { if (l.wgi_ntw == 4) { if (passes == 3) WGI(2, 4, 3, false); else WGI(2, 4, 1, false); }
                        if (l.wgi_ntw == 3) { if (passes == 3) WGI(2, 3, 3, false); else WGI(2, 3, 1, false); }
                        if (l.wgi_ntw == 2) { if (passes == 3) WGI(2, 2, 3, false); else WGI(2, 2, 1, false); } }
-        else         { if (l.wgi_ntw == 9) { if (passes == 3) WGI(4, 9, 3, false); else WGI(4, 9, 1, false); }
+        else         { // full-width tiles: 32 column tiles on eight waves (25.7 -> 21 us); the 36 tiles of a 3x3x64 layer stay on four
+                       // (six or eight waves re-read the dz fragments too often: 33.5 -> 37 us)
+                       static const bool w4 = getenv("ISDQN_WGRAD_4WAVES") != nullptr;
+                       if (l.wgi_ntw == 8 && !w4) { if (passes == 3) WGI8(4, 4, 3, false); else WGI8(4, 4, 1, false); }
+                       if (l.wgi_ntw == 9) { if (passes == 3) WGI(4, 9, 3, false); else WGI(4, 9, 1, false); }
                        if (l.wgi_ntw == 8) { if (passes == 3) WGI(4, 8, 3, false); else WGI(4, 8, 1, false); }
                        if (l.wgi_ntw == 4) { if (passes == 3) WGI(4, 4, 3, false); else WGI(4, 4, 1, false); }
                        if (l.wgi_ntw == 3) { if (passes == 3) WGI(4, 3, 3, false); else WGI(4, 3, 1, false); }
                        if (l.wgi_ntw == 2) { if (passes == 3) WGI(4, 2, 3, false); else WGI(4, 2, 1, false); } }
     }
 #undef WGI
+#undef WGI8
     *slabs_out = 0;  // (u8 with NTW 3 is not instantiated)
     return ISDQN_OK;
 }
