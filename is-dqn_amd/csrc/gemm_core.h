@@ -134,6 +134,14 @@ __device__ __forceinline__ bf16x8 read_frag(const __bf16* tile, int row0, int la
 //   __device__ void load_a(const Tile&, const ACtx&, int varying, float (&v)[8]) const   (same for b)
 //   __device__ void epilogue(const Tile&, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane) const
 //        acc[mt][nt][r] <-> C[m_wave + mt*16 + (lane>>4)*4 + r][n_wave + nt*16 + (lane&15)]
+// K groups (problems that declare `static constexpr int KG = 2`): two groups of four waves own the same output tile and
+// take alternate K steps, each with its own pair of LDS stages; they swap one row tile of partial sums through LDS and
+// each runs the epilogue on one (see conv_fwd_img_kernel).  For tilings that put one workgroup on a CU.
+template <class P, class = void>
+struct KGroupsOf { static constexpr int value = 1; };
+template <class P>
+struct KGroupsOf<P, std::void_t<decltype(P::KG)>> { static constexpr int value = P::KG; };
+
 template <class P>
 struct GemmTraits {
     static constexpr int BM = P::BM, BN = P::BN, WM = P::WM, WN = P::WN;
@@ -144,13 +152,17 @@ struct GemmTraits {
     using GA = TileGeom<BM, P::A_TR>;
     using GB = TileGeom<BN, P::B_TR>;
     static constexpr int STAGE_ELEMS = A_PLANES * GA::ELEMS + B_PLANES * GB::ELEMS;
-    static constexpr int PIPE_BYTES = 2 * STAGE_ELEMS * 2;
-    static constexpr int LDS_BYTES = PIPE_BYTES > P::EPI_LDS_BYTES ? PIPE_BYTES : P::EPI_LDS_BYTES;
+    static constexpr int KG = KGroupsOf<P>::value;
+    static constexpr int PIPE_BYTES = KG * 2 * STAGE_ELEMS * 2;
+    static constexpr int XCHG_BYTES = KG > 1 ? KG * 4 * NT * 4 * 64 * 4 : 0;  // one row tile of every wave, both directions
+    static constexpr int EPI_BYTES = P::EPI_LDS_BYTES + XCHG_BYTES;
+    static constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
 };
 
 template <class P>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
+__global__ __launch_bounds__(GEMM_THREADS * KGroupsOf<P>::value) void gemm_kernel(const P p) {
     using T = GemmTraits<P>;
+    constexpr int KG = T::KG;
     using GA = typename T::GA;
     using GB = typename T::GB;
     constexpr int MT = T::MT, NT = T::NT, PASSES = T::PASSES;
@@ -160,7 +172,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
     typename P::Tile tile;
     if (!p.tile((int)blockIdx.x, tile)) return;
 
-    const int tid = threadIdx.x;
+    const int kg = KG > 1 ? (int)threadIdx.x / GEMM_THREADS : 0;
+    const int tid = (int)threadIdx.x - kg * GEMM_THREADS;  // (group-local)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / P::WN, wn = wave % P::WN;
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
             if (GB::CHUNKS % GEMM_THREADS == 0 || b_on[i]) p.load_b(tile, bctx[i], k + b_var[i], sb[i]);
     };
     auto stash = [&](int stage) {
-        __bf16* base = smem + stage * T::STAGE_ELEMS;
+        __bf16* base = smem + (kg * 2 + stage) * T::STAGE_ELEMS;
         __bf16* a_hi = base;
         __bf16* a_lo = base + GA::ELEMS;
         __bf16* b_hi = base + T::A_PLANES * GA::ELEMS;
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
         for (int nt = 0; nt < NT; ++nt) mfma_init(acc[mt][nt]);
 
     auto compute = [&](int stage) {
-        const __bf16* base = smem + stage * T::STAGE_ELEMS;
+        const __bf16* base = smem + (kg * 2 + stage) * T::STAGE_ELEMS;
         const __bf16* a_hi = base;
         const __bf16* a_lo = base + GA::ELEMS;
         const __bf16* b_hi = base + T::A_PLANES * GA::ELEMS;
@@ -284,21 +297,46 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const P p) {
     };
 
     // ---- main loop: one barrier per K step, loads of step s+1 in flight under the MFMAs of step s ----
-    const int nsteps = (tile.k1 - tile.k0 + GEMM_BK - 1) / GEMM_BK;
+    // (K groups: group g takes steps g, g + KG, ...; a position past the last step loads zeros)
+    const int nsteps = ((tile.k1 - tile.k0 + GEMM_BK - 1) / GEMM_BK + KG - 1) / KG;
     if (nsteps > 0) {
-        fetch(tile.k0);
+        fetch(tile.k0 + kg * GEMM_BK);
         stash(0);
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
             const bool more = s + 1 < nsteps;
-            if (more) fetch(tile.k0 + (s + 1) * GEMM_BK);
+            if (more) fetch(tile.k0 + ((s + 1) * KG + kg) * GEMM_BK);
             compute(s & 1);
             mfma_drain(!more);
             if (more) stash((s + 1) & 1);
             __syncthreads();
         }
     }
-    p.epilogue(tile, acc, tile.m0 + wave_m, tile.n0 + wave_n, lane, smem_raw);
+    if constexpr (KG > 1) {
+        // group g finalizes row tile mt = g of every wave: hand the other one to the partner (behind the epilogue's
+        // own LDS area), add the partner's, and run the epilogue on a one-row-tile view
+        static_assert(KG == 2 && MT == 2, "one row tile per K group");
+        float* red = reinterpret_cast<float*>(smem_raw + P::EPI_LDS_BYTES);  // [group][wave][nt][r][lane]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float give = kg == 0 ? acc[1][nt][r] : acc[0][nt][r];
+                red[(((kg * 4 + wave) * NT + nt) * 4 + r) * 64 + lane] = give;
+            }
+        __syncthreads();
+        f32x4 mine[1][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float got = red[((((1 - kg) * 4 + wave) * NT + nt) * 4 + r) * 64 + lane];
+                mine[0][nt][r] = (kg == 0 ? acc[0][nt][r] : acc[1][nt][r]) + got;
+            }
+        p.epilogue(tile, mine, tile.m0 + wave_m + kg * 16, tile.n0 + wave_n, lane, smem_raw);
+    } else {
+        p.epilogue(tile, acc, tile.m0 + wave_m, tile.n0 + wave_n, lane, smem_raw);
+    }
 }
 
 template <class P>
@@ -312,7 +350,7 @@ static int launch_gemm(const P& p, int n_blocks, hipStream_t stream) {
         configured = true;
     }
     if (n_blocks <= 0) return ISDQN_OK;
-    hipLaunchKernelGGL(gemm_kernel<P>, dim3(n_blocks), dim3(GEMM_THREADS), T::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(gemm_kernel<P>, dim3(n_blocks), dim3(GEMM_THREADS * T::KG), T::LDS_BYTES, stream, p);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
 }

@@ -1801,7 +1801,11 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 };
                 // 128-row tiles (8 accumulators per wave).  64-row tiles fill the chip better (196 workgroups, -3 us)
                 // but are a four-accumulator kernel, and those are not run-to-run stable on gfx950
-                rc = x3 ? launch(DenseDgradLN<3, 128>{}) : launch(DenseDgradLN<1, 128>{});
+                // at most one workgroup per CU (242 at the headline size): two K groups of four waves (gemm_core.h)
+                static const bool no_kg = getenv("ISDQN_NO_KGROUPS") != nullptr;
+                const bool kg2 = !no_kg && ceil_div(B, 128) * (l.in_p / 64) <= 256 && l.out_p % 64 == 0;
+                if (kg2) rc = x3 ? launch(DenseDgradLN<3, 128, 2>{}) : launch(DenseDgradLN<1, 128, 2>{});
+                else rc = x3 ? launch(DenseDgradLN<3, 128>{}) : launch(DenseDgradLN<1, 128>{});
                 if (rc) return rc;
                 add_reduce_job(red_jobs, ws + below.part_off, ceil_div(B, 128) * (l.in_p / 64), 3 * below.out_p,
                                ws + below.red_off);

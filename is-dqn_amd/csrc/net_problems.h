@@ -196,11 +196,12 @@ struct PlainGemm {
 // workgroup's partial sums of (dgamma, dbeta, dbias).
 // ---------------------------------------------------------------------------------------------
 // BM_: 128 or 64 rows per workgroup (64 doubles the workgroup count: the 3136-column problem has only 49 column tiles)
-template <int PASSES_, int BM_ = 128>
+template <int PASSES_, int BM_ = 128, int KG_ = 1>
 struct DenseDgradLN {
     static constexpr int BM = BM_, BN = 64, WM = 4, WN = 1, PASSES = PASSES_;
+    static constexpr int KG = KG_;  // K groups (gemm_core.h): the epilogue then sees one row tile per wave, 8 waves
     static constexpr bool A_TR = false, B_TR = true;
-    static constexpr int EPI_LDS_BYTES = 4 * 3 * 64 * 4;
+    static constexpr int EPI_LDS_BYTES = 4 * KG_ * 3 * 64 * 4;
     MatSrc A, B;
     const float* z;            // [M][ldc] pre-LayerNorm conv output (flat [b][pix][64])
     const float *gamma, *beta; // nullptr: ReLU only
@@ -309,7 +310,7 @@ struct DenseDgradLN {
                 }
             }
         // partial sums: over the 4 row groups of the wave, then over the 4 waves (fixed order)
-        float* sp = reinterpret_cast<float*>(smem);  // [4 waves][3][64]
+        float* sp = reinterpret_cast<float*>(smem);  // [4 * KG waves][3][64]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             dg[nt] += __shfl_xor(dg[nt], 16); dg[nt] += __shfl_xor(dg[nt], 32);
@@ -325,8 +326,10 @@ struct DenseDgradLN {
         const int tid = threadIdx.x;
         if (tid < 3 * 64) {
             const int which = tid / 64, c = tid % 64;
-            part[((int64_t)t.wg * 3 + which) * 64 + c] =
-                sp[(0 * 3 + which) * 64 + c] + sp[(1 * 3 + which) * 64 + c] + sp[(2 * 3 + which) * 64 + c] + sp[(3 * 3 + which) * 64 + c];
+            float sum = sp[(0 * 3 + which) * 64 + c];
+#pragma unroll
+            for (int w = 1; w < 4 * KG; ++w) sum += sp[(w * 3 + which) * 64 + c];  // fixed order
+            part[((int64_t)t.wg * 3 + which) * 64 + c] = sum;
         }
     }
 };
