@@ -19,6 +19,8 @@
 //   MFMA cost instead of 16/16;  2 = same with an operand B that is exact in bf16
 //   (uint8 pixels), so its lo plane is skipped.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -348,6 +350,13 @@ static int launch_gemm(const P& p, int n_blocks, hipStream_t stream) {
             ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<P>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
         configured = true;
+        if (getenv("ISDQN_DEBUG_OCCUPANCY")) {  // development aid: workgroups per CU the runtime will co-schedule
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&gemm_kernel<P>),
+                                                             GEMM_THREADS * T::KG, T::LDS_BYTES) == hipSuccess)
+                fprintf(stderr, "[isdqn] %s: %d threads, %d B LDS -> %d workgroups per CU\n", __PRETTY_FUNCTION__,
+                        GEMM_THREADS * T::KG, T::LDS_BYTES, nb);
+        }
     }
     if (n_blocks <= 0) return ISDQN_OK;
     hipLaunchKernelGGL(gemm_kernel<P>, dim3(n_blocks), dim3(GEMM_THREADS * T::KG), T::LDS_BYTES, stream, p);
