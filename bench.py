@@ -61,8 +61,14 @@ def measured_traffic(workload, precision):
     precision, or null when there is none."""
     import glob
 
+    import re
+
+    def version(path):  # (round, v) as numbers: "v10" is newer than "v9"
+        m = re.search(r"round(\d+).*_v(\d+)\.json$", path.replace(os.sep, "/"))
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"{workload}_hbm_traffic_*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"{workload}_hbm_traffic_*.json")), key=version):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
