@@ -2,7 +2,7 @@
 
 One step is ~30 kernel launches on two HIP streams; launched eagerly the host spends ~380 us per step on
 launch API calls, about as long as the GPU needs to run them.  ``GraphedUpdate`` captures `S` consecutive
-steps (index row -> [sum-tree query] -> row gather -> learn_on_batch -> [priority write-back]) once, with
+steps (index rows -> [sum-tree query] -> row gather -> learn_on_batch -> [priority write-back]) once, with
 static buffers, and replays them: one graph launch per S steps.
 
 The draws stay on the host (numpy PCG64, the reference's stream): before a replay the next S rows of
@@ -23,36 +23,54 @@ class GraphedUpdate:
         rb._flush()
         self.block = torch.zeros(self.S, B, dtype=torch.float64 if prioritized else torch.int32, device=dev)
         self.indices = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.frame_ids = torch.zeros(B, s2, dtype=torch.int32, device=dev)
-        self.action = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.reward = torch.zeros(B, dtype=torch.float32, device=dev)
-        self.terminal = torch.zeros(B, dtype=torch.uint8, device=dev)
+        # Uniform sampling: the S steps of a replay sample an unchanged buffer with indices drawn beforehand, so their S
+        # row gathers are ONE launch over S*B rows at the head of the graph (one 6 us kernel at the head of a step
+        # less); every step then has its own static batch.  Prioritized sampling depends on the previous step's
+        # priority write-back and keeps one gather per step into a single batch.
+        n_b = 1 if prioritized else self.S
+        self.frame_ids = torch.zeros(n_b, B, s2, dtype=torch.int32, device=dev)
+        self.action = torch.zeros(n_b, B, dtype=torch.int32, device=dev)
+        self.reward = torch.zeros(n_b, B, dtype=torch.float32, device=dev)
+        self.terminal = torch.zeros(n_b, B, dtype=torch.uint8, device=dev)
         self._frames_ptr = rb._frames.data_ptr()
-        self.batch = eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids,
-                                    action=self.action, reward=self.reward, terminal=self.terminal)
+        self._make_batches()
         self.graph = None
         self._capture()
 
-    def _one(self, s: int) -> None:
+    def _make_batches(self) -> None:
         rb, eng = self.rb, self.eng
-        if self.prioritized:
-            tree = rb._sampling_distribution._sum_tree
-            tree.query_device(self.block[s], out=self.indices, unit=True)
-            idx = self.indices
-        else:
-            idx = self.block[s]
+        self.batches = [
+            eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids[i], action=self.action[i],
+                           reward=self.reward[i], terminal=self.terminal[i])
+            for i in range(self.frame_ids.shape[0])
+        ]
+
+    def _gather(self, idx, n_rows: int, slot: int) -> None:
+        rb = self.rb
         _hip.check(
             rb._lib.isdqn_replay_gather_rows(
                 _hip.ptr(rb._d_elem_frames), _hip.ptr(rb._d_elem_action), _hip.ptr(rb._d_elem_reward),
-                _hip.ptr(rb._d_elem_terminal), rb._stack_size, _hip.ptr(rb._d_index_to_slot), _hip.ptr(idx), self.B,
-                _hip.ptr(self.frame_ids), _hip.ptr(self.action), _hip.ptr(self.reward), _hip.ptr(self.terminal),
-                _hip.stream_ptr(),
+                _hip.ptr(rb._d_elem_terminal), rb._stack_size, _hip.ptr(rb._d_index_to_slot), _hip.ptr(idx), n_rows,
+                _hip.ptr(self.frame_ids[slot]), _hip.ptr(self.action[slot]), _hip.ptr(self.reward[slot]),
+                _hip.ptr(self.terminal[slot]), _hip.stream_ptr(),
             ),
             "isdqn_replay_gather_rows",
         )
-        eng.learn_on_batch(self.batch)
+
+    def _steps(self) -> None:
+        """The S steps of one replay, enqueued on the current stream."""
+        rb, eng = self.rb, self.eng
         if self.prioritized:
-            rb._sampling_distribution.update_device(idx, eng.priorities)
+            tree = rb._sampling_distribution._sum_tree
+            for s in range(self.S):
+                tree.query_device(self.block[s], out=self.indices, unit=True)
+                self._gather(self.indices, self.B, 0)
+                eng.learn_on_batch(self.batches[0])
+                rb._sampling_distribution.update_device(self.indices, eng.priorities)
+        else:
+            self._gather(self.block, self.S * self.B, 0)  # rows of all S steps: the [S][B] buffers are contiguous
+            for s in range(self.S):
+                eng.learn_on_batch(self.batches[s])
 
     def _capture(self) -> None:
         # warm-up on a side stream (lazy one-time setup inside the library must not happen during capture)
@@ -61,14 +79,13 @@ class GraphedUpdate:
         state = [t.clone() for t in (self.eng.params, self.eng.adam_m, self.eng.adam_v, self.eng.adam_count, self.eng.losses_accum)]
         tree_nodes = self.rb._sampling_distribution._sum_tree._nodes_dev.clone() if self.prioritized else None
         with torch.cuda.stream(side):
-            self._one(0)
+            self._steps()
         torch.cuda.current_stream(self.eng.device).wait_stream(side)
         torch.cuda.synchronize(self.eng.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            for s in range(self.S):
-                self._one(s)
-        # the warm-up step must not count: restore the training state
+            self._steps()
+        # the warm-up steps must not count: restore the training state
         for dst, src in zip((self.eng.params, self.eng.adam_m, self.eng.adam_v, self.eng.adam_count, self.eng.losses_accum), state):
             dst.copy_(src)
         if tree_nodes is not None:
@@ -81,8 +98,7 @@ class GraphedUpdate:
         rb._flush()
         if rb._frames.data_ptr() != self._frames_ptr:  # the frame store was re-allocated: pointers in the graph are stale
             self._frames_ptr = rb._frames.data_ptr()
-            self.batch = self.eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids,
-                                             action=self.action, reward=self.reward, terminal=self.terminal)
+            self._make_batches()
             self._capture()
         sampler = rb._sampling_distribution
         rows = sampler.draw_rows_device(self.S, self.B)
