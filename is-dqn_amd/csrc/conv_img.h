@@ -349,10 +349,61 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
         // the last barrier) and the request for slice s+2+PF.
         read_frags(0, slice(0), fr[0]);
         __syncthreads();  // every wave has read stage 0 before step 0 overwrites it with slice 2
+        // Hand-interleaved K step (fp32 layers, 24 MFMAs per step).  The MFMAs are opaque asm to the scheduler (rules
+        // above), which leaves them back to back with every other piece of the step in front of or behind the block:
+        // 384 cycles of matrix pipe in an ~880-cycle step.  A 16x16x32 MFMA holds the pipe for 16 cycles but the issue
+        // port for 4, so each one is followed by ONE micro-op of the other pieces -- a fragment read of step s+1, the
+        // hi/lo conversion of one element of slice s+2, its two LDS writes, the request for slice s+2+PF -- and a
+        // sched_barrier pins that order.  Per accumulator the pass order (hi.lo, lo.hi, hi.hi) is the old one: same bits.
+        constexpr bool INTERLEAVED = !U8 && PASSES == 3 && MTW == 4 && NT == 2 && NACC == 1 && A_PER == 1 &&
+                                     GA::CHUNKS == NTHR;
+        auto tap_offset_of = [&](int kk) {  // image offset of this lane's 8-channel chunk of K step kk (fp32 layers)
+            int kq = kk * GEMM_BK + grp * 8;
+            kq = kq < k_last ? kq : k_last;
+            uint32_t tap, ci, ky, kx;
+            g.d_cinp.divmod((uint32_t)kq, tap, ci);
+            g.d_ksz.divmod(tap, ky, kx);
+            return ((int)ky * p.Wp + (int)kx) * p.PP + (int)ci;
+        };
+        int tap_next = INTERLEAVED ? tap_offset_of(slice(1)) : 0;
         for (int s0 = 0; s0 < nsteps_p; s0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int s = s0 + u;
+                if constexpr (INTERLEAVED) {
+                    const Frags& fc = fr[u & 1];
+                    Frags& fn = fr[(u + 1) & 1];
+                    const __bf16* na_hi = a_stage + ((s + 1) & 1) * T::A_STAGE;
+                    const __bf16* na_lo = na_hi + GA::ELEMS;
+                    const int tap_off = tap_next;  // of slice(s + 1): computed in the last slot of the previous step
+                    const int slot = (u + 2) % PF;  // (a constant once the step loop is unrolled)
+                    __bf16* st_hi = a_stage + (s & 1) * T::A_STAGE + a_lds[0];
+                    __bf16* st_lo = st_hi + GA::ELEMS;
+                    bf16x8 c_hi, c_lo;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 24; ++j) {
+                        const int pass = j >> 3, nt = (j >> 2) & 1, mt = j & 3;
+                        mfma_acc(accs[0][mt][nt], pass == 1 ? fc.a_lo[mt] : fc.a_hi[mt], pass == 0 ? fc.b_lo[nt] : fc.b_hi[nt]);
+                        if (j < 4) fn.a_hi[j] = read_frag<false, GA::PITCH>(na_hi, j * 16, lane);
+                        else if (j < 8) fn.a_lo[j - 4] = read_frag<false, GA::PITCH>(na_lo, (j - 4) * 16, lane);
+                        else if (j < 10) fn.b_hi[j - 8] = *reinterpret_cast<const bf16x8*>(img + b_org[j - 8] + tap_off);
+                        else if (j < 12) fn.b_lo[j - 10] = *reinterpret_cast<const bf16x8*>(img + b_org[j - 10] + tap_off + p.plane_elems);
+                        else if (j < 20) {
+                            const float v = sa[slot][0][j - 12];
+                            const __bf16 h = (__bf16)v;
+                            c_hi[j - 12] = h;
+                            c_lo[j - 12] = (__bf16)(v - (float)h);
+                        } else if (j == 20) *reinterpret_cast<bf16x8*>(st_lo) = c_lo;
+                        else if (j == 21) *reinterpret_cast<bf16x8*>(st_hi) = c_hi;
+                        else if (j == 22) fetch(slot, slice(s + 2 + PF) * GEMM_BK);
+                        else tap_next = tap_offset_of(slice(s + 2));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    mfma_drain(s + 1 >= nsteps_p);
+                    __syncthreads();
+                    continue;
+                }
                 read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
                 mfma_step(fr[u & 1], u & 1);
                 mfma_drain(s + 1 >= nsteps_p);
