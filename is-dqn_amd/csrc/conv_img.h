@@ -389,15 +389,18 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
                         else if (j < 8) fn.a_lo[j - 4] = read_frag<false, GA::PITCH>(na_lo, (j - 4) * 16, lane);
                         else if (j < 10) fn.b_hi[j - 8] = *reinterpret_cast<const bf16x8*>(img + b_org[j - 8] + tap_off);
                         else if (j < 12) fn.b_lo[j - 10] = *reinterpret_cast<const bf16x8*>(img + b_org[j - 10] + tap_off + p.plane_elems);
-                        else if (j < 20) {
-                            const float v = sa[slot][0][j - 12];
-                            const __bf16 h = (__bf16)v;
-                            c_hi[j - 12] = h;
-                            c_lo[j - 12] = (__bf16)(v - (float)h);
-                        } else if (j == 20) *reinterpret_cast<bf16x8*>(st_lo) = c_lo;
-                        else if (j == 21) *reinterpret_cast<bf16x8*>(st_hi) = c_hi;
-                        else if (j == 22) fetch(slot, slice(s + 2 + PF) * GEMM_BK);
-                        else tap_next = tap_offset_of(slice(s + 2));
+                        else if (j < 16) {  // two elements per slot (packed convert / packed subtract)
+#pragma unroll
+                            for (int e = 2 * (j - 12); e < 2 * (j - 12) + 2; ++e) {
+                                const float v = sa[slot][0][e];
+                                const __bf16 h = (__bf16)v;
+                                c_hi[e] = h;
+                                c_lo[e] = (__bf16)(v - (float)h);
+                            }
+                        } else if (j == 16) *reinterpret_cast<bf16x8*>(st_lo) = c_lo;
+                        else if (j == 17) *reinterpret_cast<bf16x8*>(st_hi) = c_hi;
+                        else if (j == 18) fetch(slot, slice(s + 2 + PF) * GEMM_BK);
+                        else if (j == 19) tap_next = tap_offset_of(slice(s + 2));  // (nothing trails the last MFMAs)
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     mfma_drain(s + 1 >= nsteps_p);
