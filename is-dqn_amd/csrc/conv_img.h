@@ -1083,10 +1083,58 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     ISDQN_STAMP(2);
     read_frags(0, slice(0), fr[0]);
     __syncthreads();  // every wave has read stage 0 before step 0 overwrites it with slice 2
+    // hand-interleaved K step for the 64-channel layer (24 MFMAs per step), as in conv_fwd_img_kernel
+    constexpr bool INTERLEAVED = PASSES == 3 && MT == 4 && NT == 2 && NACC == 1 && A_PER == 1 && GA::CHUNKS == GEMM_THREADS;
+    auto tap_offset_of = [&](int kk) {  // dz-image offset of this lane's 8-channel chunk of K step kk
+        int kq = kk * GEMM_BK + grp * 8;
+        kq = kq < k_last ? kq : k_last;
+        uint32_t jt, co, jy_u, jx_u;
+        g.d_coutp.divmod((uint32_t)kq, jt, co);
+        p.d_T.divmod(jt, jy_u, jx_u);
+        return -((int)jy_u * p.Wd + (int)jx_u) * p.PPd + (int)co;
+    };
+    int tap_next = INTERLEAVED ? tap_offset_of(slice(1)) : 0;
     for (int s0 = 0; s0 < nsteps_p; s0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int s = s0 + u;
+            if constexpr (INTERLEAVED) {
+                const Frags& fc = fr[u & 1];
+                Frags& fn = fr[(u + 1) & 1];
+                const __bf16* na_hi = a_stage + ((s + 1) & 1) * A_STAGE;
+                const __bf16* na_lo = na_hi + GA::ELEMS;
+                const int tap_off = tap_next;  // of slice(s + 1)
+                const int slot = (u + 2) % PF;  // (a constant once the step loop is unrolled)
+                __bf16* st_hi = a_stage + (s & 1) * A_STAGE + a_lds[0];
+                __bf16* st_lo = st_hi + GA::ELEMS;
+                bf16x8 c_hi, c_lo;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jm = 0; jm < 24; ++jm) {
+                    const int pass = jm >> 3, nt = (jm >> 2) & 1, mt = jm & 3;
+                    mfma_acc(accs[0][mt][nt], pass == 1 ? fc.a_lo[mt] : fc.a_hi[mt], pass == 0 ? fc.b_lo[nt] : fc.b_hi[nt]);
+                    if (jm < 4) fn.a_hi[jm] = read_frag<true, GA::PITCH>(na_hi, jm * 16, lane);
+                    else if (jm < 8) fn.a_lo[jm - 4] = read_frag<true, GA::PITCH>(na_lo, (jm - 4) * 16, lane);
+                    else if (jm < 10) fn.b_hi[jm - 8] = *reinterpret_cast<const bf16x8*>(img + b_org[jm - 8] + tap_off);
+                    else if (jm < 12) fn.b_lo[jm - 10] = *reinterpret_cast<const bf16x8*>(img + b_org[jm - 10] + tap_off + p.dz_plane);
+                    else if (jm < 16) {
+#pragma unroll
+                        for (int e = 2 * (jm - 12); e < 2 * (jm - 12) + 2; ++e) {
+                            const float v = sa[slot][0][e];
+                            const __bf16 h = (__bf16)v;
+                            c_hi[e] = h;
+                            c_lo[e] = (__bf16)(v - (float)h);
+                        }
+                    } else if (jm == 16) *reinterpret_cast<bf16x8*>(st_lo) = c_lo;
+                    else if (jm == 17) *reinterpret_cast<bf16x8*>(st_hi) = c_hi;
+                    else if (jm == 18) fetch(slot, slice(s + 2 + PF) * GEMM_BK);
+                    else if (jm == 19) tap_next = tap_offset_of(slice(s + 2));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma_drain(s + 1 >= nsteps_p);
+                __syncthreads();
+                continue;
+            }
             read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
             mfma_step(fr[u & 1], u & 1);
             mfma_drain(s + 1 >= nsteps_p);
