@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/isdqn_hip.h"
 
@@ -56,6 +57,38 @@ struct FastDiv {
         r = n - q * d;
     }
 };
+
+// Development switches (phase stamps, ablation, environment overrides) exist only in -DISDQN_DEV builds
+// (`python is-dqn_amd/build.py --variant dev -DISDQN_DEV`): the product library reads no environment variable and has
+// no code path that skips work.
+#if defined(ISDQN_DEV)
+#define ISDQN_DEV_ENV(name) (getenv(name) != nullptr)
+#else
+#define ISDQN_DEV_ENV(name) (false)
+#endif
+
+// Process-level state of the library is keyed by HIP device: the ">64 KB of LDS" function attribute is per device, and so
+// are the weight-gradient side stream and its events.
+constexpr int ISDQN_MAX_DEVICES = 16;
+static inline int current_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= ISDQN_MAX_DEVICES) d = 0;
+    return d;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device), raised when a larger request comes
+struct LdsConfigured {
+    int bytes[ISDQN_MAX_DEVICES] = {0};
+};
+template <class F>
+static inline int ensure_dynamic_lds(F kernel, int lds_bytes, LdsConfigured& state) {
+    if (lds_bytes <= 65536) return ISDQN_OK;
+    const int d = current_device_slot();
+    if (lds_bytes > state.bytes[d]) {
+        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        state.bytes[d] = lds_bytes;
+    }
+    return ISDQN_OK;
+}
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -94,11 +94,17 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
     const ConvGeom& g = p.g;
 
     const int tid = tid_all - kg * GEMM_THREADS, lane = tid & 63, wave = tid >> 6;  // (group-local)
+#if defined(ISDQN_DEV)
 #define ISDQN_STAMP(i)                                                                               \
     if (p.stamps != nullptr && threadIdx.x == 0) {                                                  \
         p.stamps[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime();           \
         if ((i) == 0) p.stamps[(int64_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memrealtime(); \
     }
+#define ISDQN_ABLATED(bit) ((p.ablate & (bit)) != 0)
+#else
+#define ISDQN_STAMP(i)
+#define ISDQN_ABLATED(bit) (false)
+#endif
     ISDQN_STAMP(0);
     constexpr int mt0 = 0;
     int j, tile;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
     };
 
     const int nsteps_p = ((nsteps + KG - 1) / KG + PF - 1) / PF * PF;  // loop positions of one K group
-    const int rot = (p.ablate & 16) ? 0 : (int)((blockIdx.x >> 3) % (unsigned)nsteps);
+    const int rot = ISDQN_ABLATED(16) ? 0 : (int)((blockIdx.x >> 3) % (unsigned)nsteps);
     auto slice = [&](int s) {  // K step handled at this group's loop position s; positions past nsteps read zeros
         const int gs = s * KG + kg;
         const int k = gs + rot;
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
     // FILL_BATCH chunk loads are issued back to back before the first one is consumed: a plain
     // load -> convert -> store loop is one L2/HBM round trip per iteration.
     constexpr int FILL_BATCH = (U8 ? 8 : 12) / KG;  // chunks in flight per thread: the 21x21x32 image (10.6 chunks) in ONE round trip
-    if (p.ablate & 1) {
+    if (ISDQN_ABLATED(1)) {
     } else if constexpr (U8) {
         // planar: img[c][lr][Wp], chunk = 8 consecutive padded columns
         const int cpr = p.Wp / 8;                       // chunks per row (Wp is a multiple of 8)
@@ -256,17 +262,11 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
         b_org[nt] = U8 ? (ly0 * p.Wp + lx0) : (ly0 * p.Wp + lx0) * p.PP;
     }
 
-    // With two channel tiles a wave has only four accumulators, and four-accumulator kernels are not run-to-run stable
-    // on gfx950: the K steps then alternate between two accumulator sets (even / odd steps),
-    // eight live accumulators and no extra MFMA, added up once in front of the epilogue.
-    constexpr int NACC = (MTW * NT <= 4) ? 2 : 1;
-    f32x4 accs[NACC][MTW][NT];
+    f32x4 acc[MTW][NT];
 #pragma unroll
-    for (int a = 0; a < NACC; ++a)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) mfma_init(accs[a][mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) mfma_init(acc[mt][nt]);
 
 
     // Fragments of one K step: MTW weight tiles and NT pixel tiles, each hi (+ lo).  Two sets alternate so that the
@@ -310,17 +310,16 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
             }
         }
     };
-    auto mfma_step = [&](const Frags& f, int step_parity) {  // (folds to a constant once the step loop is unrolled)
-        const int a = NACC == 2 ? step_parity : 0;
+    auto mfma_step = [&](const Frags& f) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 if constexpr (PASSES >= 3)
-                    mfma_acc(accs[a][mt][nt], f.a_hi[mt], f.b_lo[nt]);
+                    mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_lo[nt]);
                 if constexpr (PASSES >= 2)
-                    mfma_acc(accs[a][mt][nt], f.a_lo[mt], f.b_hi[nt]);
-                mfma_acc(accs[a][mt][nt], f.a_hi[mt], f.b_hi[nt]);
+                    mfma_acc(acc[mt][nt], f.a_lo[mt], f.b_hi[nt]);
+                mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_hi[nt]);
             }
     };
 
@@ -342,7 +341,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
     fetch(1, slice(PF + 1) * GEMM_BK);
     __syncthreads();  // image and the first two weight slices visible
     ISDQN_STAMP(2);
-    if (!(p.ablate & 2)) {
+    if (!ISDQN_ABLATED(2)) {
         // One barrier per K step, and everything between two barriers is independent, so the compiler is free to
         // interleave it: the fragment reads of step s+1 (stage (s+1)&1, written during step s-1), the MFMAs of step s
         // (fragments read during step s-1), the conversion of slice s+2 into stage s&1 (whose readers finished before
@@ -355,7 +354,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
         // port for 4, so each one is followed by ONE micro-op of the other pieces -- a fragment read of step s+1, the
         // hi/lo conversion of one element of slice s+2, its two LDS writes, the request for slice s+2+PF -- and a
         // sched_barrier pins that order.  Per accumulator the pass order (hi.lo, lo.hi, hi.hi) is the old one: same bits.
-        constexpr bool INTERLEAVED = !U8 && PASSES == 3 && MTW == 4 && NT == 2 && NACC == 1 && A_PER == 1 &&
+        constexpr bool INTERLEAVED = !U8 && PASSES == 3 && MTW == 4 && NT == 2 && A_PER == 1 &&
                                      GA::CHUNKS == NTHR;
         auto tap_offset_of = [&](int kk) {  // image offset of this lane's 8-channel chunk of K step kk (fp32 layers)
             int kq = kk * GEMM_BK + grp * 8;
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
 #pragma unroll
                     for (int j = 0; j < 24; ++j) {
                         const int pass = j >> 3, nt = (j >> 2) & 1, mt = j & 3;
-                        mfma_acc(accs[0][mt][nt], pass == 1 ? fc.a_lo[mt] : fc.a_hi[mt], pass == 0 ? fc.b_lo[nt] : fc.b_hi[nt]);
+                        mfma_acc(acc[mt][nt], pass == 1 ? fc.a_lo[mt] : fc.a_hi[mt], pass == 0 ? fc.b_lo[nt] : fc.b_hi[nt]);
                         if (j < 4) fn.a_hi[j] = read_frag<false, GA::PITCH>(na_hi, j * 16, lane);
                         else if (j < 8) fn.a_lo[j - 4] = read_frag<false, GA::PITCH>(na_lo, (j - 4) * 16, lane);
                         else if (j < 10) fn.b_hi[j - 8] = *reinterpret_cast<const bf16x8*>(img + b_org[j - 8] + tap_off);
@@ -403,13 +402,11 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
                         else if (j == 19) tap_next = tap_offset_of(slice(s + 2));  // (nothing trails the last MFMAs)
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    mfma_drain(s + 1 >= nsteps_p);
                     __syncthreads();
                     continue;
                 }
                 read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
-                mfma_step(fr[u & 1], u & 1);
-                mfma_drain(s + 1 >= nsteps_p);
+                mfma_step(fr[u & 1]);
                 stash((u + 2) % PF, s & 1);
                 fetch((u + 2) % PF, slice(s + 2 + PF) * GEMM_BK);
                 // Issue order for the block: a 16x16x32 MFMA occupies the matrix pipe for 16 cycles but the issue port
@@ -427,14 +424,6 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
         }
     }
     ISDQN_STAMP(3);  // K loop done
-    f32x4 acc[MTW][NT];
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc[mt][nt] = accs[0][mt][nt];
-            if constexpr (NACC == 2) acc[mt][nt] += accs[1][mt][nt];
-        }
     if constexpr (KG > 1) {
         // The two groups hold partial sums of the same tile.  Group g finalizes pixel tile nt = g of every wave: each
         // wave hands the OTHER tile to its partner through LDS (the image is dead: the K loop ended with a barrier).
@@ -457,7 +446,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
                 else acc[mt][1][r] += got;
             }
     }
-    if (p.ablate & 4) {
+    if (ISDQN_ABLATED(4)) {
         if (acc[0][0][0] == 12345.678f) p.act[0] = 1.f;  // keep the accumulators alive
         return;
     }
@@ -526,23 +515,22 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
         }
     }
     ISDQN_STAMP(4);  // epilogue stores issued
+#if defined(ISDQN_DEV)
     if (p.stamps != nullptr) {
         __builtin_amdgcn_s_waitcnt(0);
         ISDQN_STAMP(5);  // stores retired
     }
+#endif
 #undef ISDQN_STAMP
+#undef ISDQN_ABLATED
 }
 
 template <int MT, int PASSES, bool U8, int KG = 1>
 static int launch_conv_fwd_img(const ConvImgParams& p, hipStream_t st) {
     using T = ConvImgTraits<MT, PASSES, U8>;
     const int lds = (KG * 2 * T::A_STAGE + T::B_PLANES * p.plane_elems) * 2;
-    static int configured_for = 0;
-    if (lds > 65536 && lds > configured_for) {
-        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_img_kernel<MT, PASSES, U8, KG>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured_for = lds;
-    }
+    static LdsConfigured configured;
+    if (int rc = ensure_dynamic_lds(&conv_fwd_img_kernel<MT, PASSES, U8, KG>, lds, configured)) return rc;
     hipLaunchKernelGGL((conv_fwd_img_kernel<MT, PASSES, U8, KG>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS * KG), lds,
                        st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
@@ -783,7 +771,6 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
                     mfma_acc(acc[mt][t], fa_hi[mt], fb_hi);
                 }
             }
-            mfma_drain(ks + 1 == nsteps && j + 1 == j1);
         }
     }
 
@@ -806,12 +793,8 @@ static int launch_conv_wgrad_img(const ConvWgradImgParams& p, int n_img_groups, 
     constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
     constexpr int B_PLANES = (PASSES >= 3) ? 2 : 1;
     const int lds = (A_PLANES * p.dz_plane + B_PLANES * p.in_plane) * 2;
-    static int configured_for = 0;
-    if (lds > 65536 && lds > configured_for) {
-        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured_for = lds;
-    }
+    static LdsConfigured configured;
+    if (int rc = ensure_dynamic_lds(&conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>, lds, configured)) return rc;
     hipLaunchKernelGGL((conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>), dim3(n_img_groups * p.n_col_groups),
                        dim3(64 * WV), lds, st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
@@ -867,11 +850,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     __shared__ float s_part[4][3][64];
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4;
+#if defined(ISDQN_DEV)
 #define ISDQN_STAMP(i)                                                                               \
     if (p.stamps != nullptr && threadIdx.x == 0) {                                                  \
         p.stamps[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime();           \
         if ((i) == 0) p.stamps[(int64_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memrealtime(); \
     }
+#define ISDQN_ABLATED(bit) ((p.ablate & (bit)) != 0)
+#else
+#define ISDQN_STAMP(i)
+#define ISDQN_ABLATED(bit) (false)
+#endif
     ISDQN_STAMP(0);
 
     int j, tl;
@@ -1006,16 +995,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
         b_org[nt] = ((oyb + p.bt) * p.Wd + oxb + p.bt) * p.PPd;
     }
 
-    // two accumulator sets (even / odd K steps) when a wave would otherwise have only four accumulators: see
-    // conv_fwd_img_kernel
-    constexpr int NACC = (MT * NT <= 4) ? 2 : 1;
-    f32x4 accs[NACC][MT][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int a = 0; a < NACC; ++a)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) mfma_init(accs[a][mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) mfma_init(acc[mt][nt]);
 
     struct Frags {
         bf16x8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
@@ -1043,17 +1027,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
             if constexpr (PASSES >= 3) f.b_lo[nt] = *reinterpret_cast<const bf16x8*>(src + p.dz_plane);
         }
     };
-    auto mfma_step = [&](const Frags& f, int step_parity) {
-        const int a = NACC == 2 ? step_parity : 0;
+    auto mfma_step = [&](const Frags& f) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (PASSES >= 3)
-                    mfma_acc(accs[a][mt][nt], f.a_hi[mt], f.b_lo[nt]);
+                    mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_lo[nt]);
                 if constexpr (PASSES >= 2)
-                    mfma_acc(accs[a][mt][nt], f.a_lo[mt], f.b_hi[nt]);
-                mfma_acc(accs[a][mt][nt], f.a_hi[mt], f.b_hi[nt]);
+                    mfma_acc(acc[mt][nt], f.a_lo[mt], f.b_hi[nt]);
+                mfma_acc(acc[mt][nt], f.a_hi[mt], f.b_hi[nt]);
             }
     };
 
@@ -1084,7 +1067,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     read_frags(0, slice(0), fr[0]);
     __syncthreads();  // every wave has read stage 0 before step 0 overwrites it with slice 2
     // hand-interleaved K step for the 64-channel layer (24 MFMAs per step), as in conv_fwd_img_kernel
-    constexpr bool INTERLEAVED = PASSES == 3 && MT == 4 && NT == 2 && NACC == 1 && A_PER == 1 && GA::CHUNKS == GEMM_THREADS;
+    constexpr bool INTERLEAVED = PASSES == 3 && MT == 4 && NT == 2 && A_PER == 1 && GA::CHUNKS == GEMM_THREADS;
     auto tap_offset_of = [&](int kk) {  // dz-image offset of this lane's 8-channel chunk of K step kk
         int kq = kk * GEMM_BK + grp * 8;
         kq = kq < k_last ? kq : k_last;
@@ -1112,7 +1095,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
 #pragma unroll
                 for (int jm = 0; jm < 24; ++jm) {
                     const int pass = jm >> 3, nt = (jm >> 2) & 1, mt = jm & 3;
-                    mfma_acc(accs[0][mt][nt], pass == 1 ? fc.a_lo[mt] : fc.a_hi[mt], pass == 0 ? fc.b_lo[nt] : fc.b_hi[nt]);
+                    mfma_acc(acc[mt][nt], pass == 1 ? fc.a_lo[mt] : fc.a_hi[mt], pass == 0 ? fc.b_lo[nt] : fc.b_hi[nt]);
                     if (jm < 4) fn.a_hi[jm] = read_frag<true, GA::PITCH>(na_hi, jm * 16, lane);
                     else if (jm < 8) fn.a_lo[jm - 4] = read_frag<true, GA::PITCH>(na_lo, (jm - 4) * 16, lane);
                     else if (jm < 10) fn.b_hi[jm - 8] = *reinterpret_cast<const bf16x8*>(img + b_org[jm - 8] + tap_off);
@@ -1131,13 +1114,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
                     else if (jm == 19) tap_next = tap_offset_of(slice(s + 2));
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                mfma_drain(s + 1 >= nsteps_p);
                 __syncthreads();
                 continue;
             }
             read_frags((s + 1) & 1, slice(s + 1), fr[(u + 1) & 1]);
-            mfma_step(fr[u & 1], u & 1);
-            mfma_drain(s + 1 >= nsteps_p);
+            mfma_step(fr[u & 1]);
             stash((u + 2) % PF, s & 1);
             fetch((u + 2) % PF, slice(s + 2 + PF) * GEMM_BK);
             constexpr int N_MFMA = MT * NT * (PASSES >= 3 ? 3 : PASSES);
@@ -1152,14 +1133,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     }
 
     ISDQN_STAMP(3);  // K loop done
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc[mt][nt] = accs[0][mt][nt];
-            if constexpr (NACC == 2) acc[mt][nt] += accs[1][mt][nt];
-        }
     // ---- epilogue: LayerNorm + ReLU backward of the layer below, per input pixel (column) ----
     float ga[MT][4], be[MT][4];
 #pragma unroll
@@ -1268,11 +1241,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
             s_part[0][which][c] + s_part[1][which][c] + s_part[2][which][c] + s_part[3][which][c];
     }
     ISDQN_STAMP(4);  // epilogue stores issued
+#if defined(ISDQN_DEV)
     if (p.stamps != nullptr) {
         __builtin_amdgcn_s_waitcnt(0);
         ISDQN_STAMP(5);
     }
+#endif
 #undef ISDQN_STAMP
+#undef ISDQN_ABLATED
 }
 
 // Deterministic reduction of per-workgroup partial rows: out[c] = sum_r part[r][c].  One workgroup per 8
@@ -1325,12 +1301,8 @@ static int launch_conv_dgrad_img(const ConvDgradImgParams& p, hipStream_t st) {
     constexpr int B_PLANES = PASSES >= 3 ? 2 : 1;
     using GA = TileGeom<MT * 16, true>;
     const int lds = (2 * A_PLANES * GA::ELEMS + B_PLANES * p.dz_plane) * 2;
-    static int configured_for = 0;
-    if (lds > 65536 && lds > configured_for) {
-        ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dgrad_img_kernel<MT, PASSES>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured_for = lds;
-    }
+    static LdsConfigured configured;
+    if (int rc = ensure_dynamic_lds(&conv_dgrad_img_kernel<MT, PASSES>, lds, configured)) return rc;
     hipLaunchKernelGGL((conv_dgrad_img_kernel<MT, PASSES>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS), lds, st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;

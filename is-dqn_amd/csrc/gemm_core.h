@@ -67,43 +67,16 @@ struct TileGeom {
     static constexpr int PER_THREAD = (CHUNKS + GEMM_THREADS - 1) / GEMM_THREADS;
 };
 
-// acc += A * B on the matrix pipe, IN PLACE.  The MFMA is issued through inline asm with the accumulator as a tied
-// read-write operand, so vDst == SrcC always.  With the builtin, hipcc (ROCm 7.2) renames accumulators when few are
-// live (the four-accumulator MT = 2 kernels, and the pipelined 8-accumulator loops), emitting e.g.
-//     v_mfma a[4:7],  A_lo, B, a[4:7]
-//     (four v_accvgpr_read)
-//     v_mfma a[8:11], A_hi, B, a[4:7]      <- SrcC = result of the MFMA a few instructions earlier, other vDst
-//     v_accvgpr_write a4..a7, ...          <- over registers that MFMA may still be writing
-// In-place chains are interlocked by the hardware; this renamed form relies on compiler-inserted wait states, and on
-// gfx950 they were not enough: about 1 % of workgroups (more when waves share a SIMD) produced a tile that lacked one
-// MFMA pass.  Found by the full-size run-to-run determinism test (tests/test_gpu_fullsize_properties.py).
-// Consequences of the asm: the compiler no longer knows these are MFMAs, so (1) the wait before the accumulators are
-// read is ours -- mfma_drain() below, INSIDE the loop's last iteration -- and (2) operands written by VALU need a few
-// wait states in front of the MFMA (only the head chain converts operands in registers; everywhere else they come
-// from ds_reads, whose s_waitcnt the compiler still inserts because it tracks the asm's register operands).
-// (3) the same holds between the zero-initialisation of an accumulator (v_accvgpr_write) and the first MFMA that
-// reads it: mfma_init() pads behind the initialisation.
-__device__ __forceinline__ void mfma_init(f32x4& acc) {
-    acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_nop 1" : "+a"(acc));
-}
+// acc += A * B on the matrix pipe (v_mfma_f32_16x16x32_bf16), through the BUILTIN, so that hipcc's hazard recogniser
+// sees every MFMA and pads its dependencies itself (VALU / v_accvgpr_write -> MFMA operand: 2 wait states; MFMA result ->
+// any other reader: passes + 4; scripts/isa_lint.py re-checks that table on the final assembly).  Round 1 issued the
+// MFMAs through inline asm with hand-placed s_nops because "tiles lacking one MFMA pass" were blamed on compiler-renamed
+// accumulators; round 2 traced the only reproducible instability to SLP-vectorised packed-fp32 epilogue code instead
+// (the library is built with -fno-slp-vectorize), and the builtin form is bit-stable in the same
+// hunts (0 differing steps in 3000 + 300 + 300) -- so the asm, its pads and the "two accumulator sets" rule are gone.
+__device__ __forceinline__ void mfma_init(f32x4& acc) { acc = f32x4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ void mfma_acc(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-
-// Wait states between the last MFMA of a K loop and the first read of its accumulators.  hipcc (ROCm 7.2) copies the
-// accumulators out of the AGPRs (v_accvgpr_read) in the loop's EXIT block, i.e. directly behind the final
-// v_mfma_f32_16x16x32_bf16 of the loop body and the closing barrier, with whatever s_nops its hazard table asks for.
-// On gfx950 that was not enough: in roughly 1 % of workgroups -- more often the more waves share a SIMD -- a tile came
-// back without its last MFMA contribution.  Found by the full-size run-to-run determinism test
-// (tests/test_gpu_fullsize_properties.py) and bisected to exactly this (the same kernel with an epilogue that first
-// waits on global loads was bit-stable; padding placed after the loop lands BEHIND the compiler's copies and does
-// nothing).  So the padding goes INSIDE the loop body, behind the MFMAs of the last iteration: 32 cycles cover an
-// 8-pass MFMA that had to queue behind another wave's.  `last` must be wave-uniform.
-__device__ __forceinline__ void mfma_drain(bool last = true) {
-    __builtin_amdgcn_sched_barrier(0);
-    if (last) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
 
 // Fragment of 16 rows x 32 k for lane `lane`: element j <-> (row = row0 + (lane&15), k = 8*(lane>>4) + j).
@@ -309,7 +282,6 @@ __global__ __launch_bounds__(GEMM_THREADS * KGroupsOf<P>::value) void gemm_kerne
             const bool more = s + 1 < nsteps;
             if (more) fetch(tile.k0 + ((s + 1) * KG + kg) * GEMM_BK);
             compute(s & 1);
-            mfma_drain(!more);
             if (more) stash((s + 1) & 1);
             __syncthreads();
         }
@@ -344,20 +316,20 @@ __global__ __launch_bounds__(GEMM_THREADS * KGroupsOf<P>::value) void gemm_kerne
 template <class P>
 static int launch_gemm(const P& p, int n_blocks, hipStream_t stream) {
     using T = GemmTraits<P>;
-    static bool configured = false;
-    if (!configured) {
-        if (T::LDS_BYTES > 65536)
-            ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<P>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        configured = true;
-        if (getenv("ISDQN_DEBUG_OCCUPANCY")) {  // development aid: workgroups per CU the runtime will co-schedule
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&gemm_kernel<P>),
-                                                             GEMM_THREADS * T::KG, T::LDS_BYTES) == hipSuccess)
-                fprintf(stderr, "[isdqn] %s: %d threads, %d B LDS -> %d workgroups per CU\n", __PRETTY_FUNCTION__,
-                        GEMM_THREADS * T::KG, T::LDS_BYTES, nb);
-        }
+    static LdsConfigured configured;
+    int rc = ensure_dynamic_lds(&gemm_kernel<P>, T::LDS_BYTES, configured);
+    if (rc) return rc;
+#if defined(ISDQN_DEV)
+    static bool reported = false;
+    if (!reported && getenv("ISDQN_DEBUG_OCCUPANCY")) {  // workgroups per CU the runtime will co-schedule
+        reported = true;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&gemm_kernel<P>),
+                                                         GEMM_THREADS * T::KG, T::LDS_BYTES) == hipSuccess)
+            fprintf(stderr, "[isdqn] %s: %d threads, %d B LDS -> %d workgroups per CU\n", __PRETTY_FUNCTION__,
+                    GEMM_THREADS * T::KG, T::LDS_BYTES, nb);
     }
+#endif
     if (n_blocks <= 0) return ISDQN_OK;
     hipLaunchKernelGGL(gemm_kernel<P>, dim3(n_blocks), dim3(GEMM_THREADS * T::KG), T::LDS_BYTES, stream, p);
     ISDQN_HIP_CHECK(hipGetLastError());

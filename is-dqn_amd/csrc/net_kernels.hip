@@ -6,6 +6,8 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <atomic>
+
 #include "conv_img.h"
 #include "net_plan.h"
 #include "net_problems.h"
@@ -468,11 +470,15 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
     float* s_pre = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(s_bias + p.Op) + 15) & ~(uintptr_t)15);  // [2 * SMAX][Fp] hidden pre-activations, 16-B aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if defined(ISDQN_DEV)
 #define HC_STAMP(i)                                                                                     \
     if (p.stamps != nullptr && threadIdx.x == 0) {                                                     \
         p.stamps[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime();              \
         if ((i) == 0) p.stamps[(int64_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memrealtime(); \
     }
+#else
+#define HC_STAMP(i)
+#endif
     HC_STAMP(0);
     const int S = p.S, b0 = (int)blockIdx.x * S;
     const int Fp = p.Fp, Op = p.Op, K = p.K, A = p.A;
@@ -632,7 +638,6 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
             const int pair = item / nks, ksi = item - pair * nks, ksb = wave + 16 * ksi;
             if (ksi == 0) {
                 acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                asm volatile("s_nop 7" : "+a"(acc[0]), "+a"(acc[1]));  // accumulator init (VALU) -> asm MFMA: no compiler padding
             }
 #pragma unroll
             for (int u = 0; u < HC_KU; ++u) {
@@ -645,21 +650,16 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
                     bf16x8 bh, bl;
                     if constexpr (PASSES >= 2) {
                         split8(v[t][u], bh, bl);
-                        // VALU-written operands -> asm MFMA: no compiler hazard handling, and the pad must be tied
-                        // to the operands or the scheduler sinks the conversions below it
-                        asm volatile("s_nop 4" : "+v"(bh), "+v"(bl));
                         if constexpr (PASSES >= 3)
                             mfma_acc(acc[t], ah, bl);
                         mfma_acc(acc[t], al, bh);
                     } else {
                         round8(v[t][u], bh);
-                        asm volatile("s_nop 4" : "+v"(bh));
                     }
                     mfma_acc(acc[t], ah, bh);
                 }
             }
             const bool last = ksi + 1 == nks;
-            mfma_drain(last);
             if (last) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -1039,6 +1039,7 @@ __global__ void argmax_kernel(const float* __restrict__ q, int A, int head, int*
 // Host orchestration
 // =============================================================================================
 // profiling hook (not in the public header): phase stamps of the image-resident forward kernel of one layer
+#if defined(ISDQN_DEV)
 static long long* g_stamps = nullptr;
 static int g_stamp_layer = -1;
 static char g_stamp_name[32] = "";
@@ -1048,6 +1049,12 @@ extern "C" int isdqn_debug_set_stamps(void* buf, const char* layer_name) {
     snprintf(g_stamp_name, sizeof(g_stamp_name), "%s", layer_name ? layer_name : "");
     return ISDQN_OK;
 }
+static long long* stamps_for(const char* kernel_tag) {
+    return (g_stamp_layer >= 0 && strcmp(kernel_tag, g_stamp_name) == 0) ? g_stamps : nullptr;
+}
+#else
+static long long* stamps_for(const char*) { return nullptr; }
+#endif
 
 static ConvGeom conv_geom(const Layer& l) {
     ConvGeom g;
@@ -1109,11 +1116,11 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     ip.d_chunk = FastDiv((uint32_t)(l.is_u8 ? ip.Wp / 8 : l.cin_p / 8));
     ip.d_Wp = FastDiv((uint32_t)ip.Wp);
     ip.d_R = FastDiv((uint32_t)ip.R);
-    ip.stamps = (g_stamp_layer >= 0 && strcmp(l.name, g_stamp_name) == 0) ? g_stamps : nullptr;
-    {
-        const char* e = getenv("ISDQN_ABLATE");
-        ip.ablate = e ? atoi(e) : 0;
-    }
+    ip.stamps = stamps_for(l.name);
+    ip.ablate = 0;
+#if defined(ISDQN_DEV)
+    if (const char* e = getenv("ISDQN_ABLATE")) ip.ablate = atoi(e);
+#endif
     *done = true;
     if (l.is_u8) {
         if (passes == 2) return mt == 2 ? launch_conv_fwd_img<2, 2, true>(ip, st) : launch_conv_fwd_img<4, 2, true>(ip, st);
@@ -1122,7 +1129,7 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     // An image that leaves room for one workgroup per CU only (more than half of the 160 KB) runs with two K groups of
     // four waves, if the second pair of weight stages still fits and the accumulator exchange fits the image area.
     const int stage_bytes = (passes >= 2 ? 2 : 1) * (mt * 16) * 48 * 2 * 2;  // two stages of one K group
-    static const bool no_kg = getenv("ISDQN_NO_KGROUPS") != nullptr;
+    static const bool no_kg = ISDQN_DEV_ENV("ISDQN_NO_KGROUPS");
     const bool kg2 = !no_kg && mt == 4 && lds > 80 * 1024 && lds + stage_bytes <= 150 * 1024 &&
                      mt * 16 * 128 * 4 <= lds - stage_bytes && l.K >= 8 * GEMM_BK;
     if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false>(ip, st)
@@ -1367,7 +1374,7 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
                        if (l.wgi_ntw == 2) { if (passes == 3) WGI(2, 2, 3, false); else WGI(2, 2, 1, false); } }
         else         { // full-width tiles: 32 column tiles on eight waves (25.7 -> 21 us); the 36 tiles of a 3x3x64 layer stay on four
                        // (six or eight waves re-read the dz fragments too often: 33.5 -> 37 us)
-                       static const bool w4 = getenv("ISDQN_WGRAD_4WAVES") != nullptr;
+                       static const bool w4 = ISDQN_DEV_ENV("ISDQN_WGRAD_4WAVES");
                        if (l.wgi_ntw == 8 && !w4) { if (passes == 3) WGI8(4, 4, 3, false); else WGI8(4, 4, 1, false); }
                        if (l.wgi_ntw == 9) { if (passes == 3) WGI(4, 9, 3, false); else WGI(4, 9, 1, false); }
                        if (l.wgi_ntw == 8) { if (passes == 3) WGI(4, 8, 3, false); else WGI(4, 8, 1, false); }
@@ -1416,7 +1423,11 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
     dp.d_chunk = FastDiv((uint32_t)(l.cout_p / 8));
     dp.d_Wd = FastDiv((uint32_t)dp.Wd);
     dp.d_T = FastDiv((uint32_t)dp.T);
-    dp.stamps = (g_stamp_layer >= 0 && strncmp(g_stamp_name, "dgrad:", 6) == 0 && strcmp(l.name, g_stamp_name + 6) == 0) ? g_stamps : nullptr;
+    {
+        char tag[32];
+        snprintf(tag, sizeof(tag), "dgrad:%s", l.name);
+        dp.stamps = stamps_for(tag);
+    }
     dp.n_classes = l.stride * l.stride;
     int acc = 0;
     for (int c = 0; c < dp.n_classes; ++c) {
@@ -1556,29 +1567,31 @@ extern "C" int isdqn_net_forward(const isdqn_net_config* cfg, const float* param
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t ev[2 * MAX_LAYERS + 4];
-    int n_ev = 0, next = 0;
-    bool ok = false;
+    int n_ev = 0;
+    std::atomic<unsigned> next{0};  // several agents / host threads of one process may share a device's pool
+    std::atomic<int> state{0};      // 0 = not created, 1 = being created, 2 = ready, -1 = unavailable
 };
 static SideStream* side_stream() {
-    static SideStream per_dev[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideStream& s = per_dev[dev];
-    if (!s.ok) {
-        const char* e = getenv("ISDQN_SINGLE_STREAM");
-        if (e && atoi(e)) return nullptr;
-        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    static SideStream per_dev[ISDQN_MAX_DEVICES];
+    if (ISDQN_DEV_ENV("ISDQN_SINGLE_STREAM")) return nullptr;
+    SideStream& s = per_dev[current_device_slot()];
+    int st = s.state.load(std::memory_order_acquire);
+    if (st == 2) return &s;
+    if (st == -1) return nullptr;
+    int expected = 0;
+    if (s.state.compare_exchange_strong(expected, 1)) {
+        bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
         s.n_ev = 2 * MAX_LAYERS + 4;
-        for (int i = 0; i < s.n_ev; ++i)
-            if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        s.ok = true;
+        for (int i = 0; ok && i < s.n_ev; ++i) ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
+        s.state.store(ok ? 2 : -1, std::memory_order_release);
+        return ok ? &s : nullptr;
     }
-    return &s;
+    while ((st = s.state.load(std::memory_order_acquire)) == 1) {}  // another thread is creating it
+    return st == 2 ? &s : nullptr;
 }
 // make `waiter` wait for everything enqueued so far on `signaller`
 static int chain(SideStream* ss, hipStream_t signaller, hipStream_t waiter) {
-    hipEvent_t e = ss->ev[ss->next];
-    ss->next = (ss->next + 1) % ss->n_ev;
+    hipEvent_t e = ss->ev[ss->next.fetch_add(1, std::memory_order_relaxed) % (unsigned)ss->n_ev];
     ISDQN_HIP_CHECK(hipEventRecord(e, signaller));
     ISDQN_HIP_CHECK(hipStreamWaitEvent(waiter, e, 0));
     return ISDQN_OK;
@@ -1608,7 +1621,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     const Layer& hid = P.L[P.n_layers >= 2 ? P.n_layers - 2 : 0];
     const Layer& head = P.L[P.n_layers - 1];
     int hc_S = 0, hc_wg = 0;
-    static const bool hc_disabled = getenv("ISDQN_NO_HEAD_CHAIN") != nullptr;
+    static const bool hc_disabled = ISDQN_DEV_ENV("ISDQN_NO_HEAD_CHAIN");
     if (learn && !hc_disabled && P.n_layers >= 2 && hid.kind == 1 && !hid.is_head && hid.has_relu &&
         hid.out_p <= HC_THREADS * HC_MAX_COLS && hid.out_p % 8 == 0) {
         // transitions per workgroup: the per-transition phases scale with S (the kernel is instruction-issue bound) while
@@ -1655,16 +1668,12 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         hp.q_values = qv; hp.targets = tg; hp.priorities = priorities;
         hp.loss_part = loss_part; hp.dbh_part = dbh_part;
         hp.adam_count = adam_count; hp.b1 = cfg->adam_b1; hp.b2 = cfg->adam_b2; hp.adam_consts = adam_consts;
-        hp.stamps = (g_stamp_layer >= 0 && strcmp(g_stamp_name, "head_chain") == 0) ? g_stamps : nullptr;
+        hp.stamps = stamps_for("head_chain");
         const int lds = head_chain_lds_bytes(hid.out_p, P.nha_p, K, x3 ? 3 : 1, hc_S);
         const int cols = ceil_div(hid.out_p, HC_THREADS) <= 1 ? 1 : ceil_div(hid.out_p, HC_THREADS) <= 2 ? 2 : 4;
         auto launch_hc = [&](auto kern, int slot) -> int {
-            static int configured[18] = {0};
-            if (lds > 65536 && lds > configured[slot]) {
-                ISDQN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                configured[slot] = lds;
-            }
+            static LdsConfigured configured[18];
+            if (int rc2 = ensure_dynamic_lds(kern, lds, configured[slot])) return rc2;
             hipLaunchKernelGGL(kern, dim3(hc_wg), dim3(HC_THREADS), lds, st, hp);
             ISDQN_HIP_CHECK(hipGetLastError());
             return ISDQN_OK;
@@ -1802,12 +1811,20 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 // 128-row tiles (8 accumulators per wave).  64-row tiles fill the chip better (196 workgroups, -3 us)
                 // but are a four-accumulator kernel, and those are not run-to-run stable on gfx950
                 // at most one workgroup per CU (242 at the headline size): two K groups of four waves (gemm_core.h)
-                static const bool no_kg = getenv("ISDQN_NO_KGROUPS") != nullptr;
+                static const bool no_kg = ISDQN_DEV_ENV("ISDQN_NO_KGROUPS");
                 const bool kg2 = !no_kg && ceil_div(B, 128) * (l.in_p / 64) <= 256 && l.out_p % 64 == 0;
+                // ISDQN_DGRAD64 (development): 64-row tiles, one K group
+#if defined(ISDQN_DGRAD64)
+                (void)kg2;
+                rc = x3 ? launch(DenseDgradLN<3, 64>{}) : launch(DenseDgradLN<1, 64>{});
+                constexpr int DG_BM = 64;
+#else
                 if (kg2) rc = x3 ? launch(DenseDgradLN<3, 128, 2>{}) : launch(DenseDgradLN<1, 128, 2>{});
                 else rc = x3 ? launch(DenseDgradLN<3, 128>{}) : launch(DenseDgradLN<1, 128>{});
+                constexpr int DG_BM = 128;
+#endif
                 if (rc) return rc;
-                add_reduce_job(red_jobs, ws + below.part_off, ceil_div(B, 128) * (l.in_p / 64), 3 * below.out_p,
+                add_reduce_job(red_jobs, ws + below.part_off, ceil_div(B, DG_BM) * (l.in_p / 64), 3 * below.out_p,
                                ws + below.red_off);
                 dz_fused = true;
             }

@@ -1,6 +1,6 @@
-"""BASELINE.json's full sizes (configs[1]: B=256, K=9, A=9, cnn 32/64/64/512 + LayerNorm) are too big for the CPU
-oracle to follow step by step in seconds, so the HIP path is checked there through properties that do not depend
-on the size:
+"""BASELINE.json's full sizes (configs[1]/[2]: B=256, K=9, A=9 and configs[4]: B=1024, K=32, A=4; cnn 32/64/64/512 +
+LayerNorm) are too big for the CPU oracle to follow step by step in seconds, so the HIP path is checked there through
+properties that do not depend on the size (every test runs at both shapes):
 
 * run-to-run bitwise determinism of a learn step (every reduction in the path has a fixed order);
 * the fused learn path (head chain kernel) against the independent forward-only path (head GEMM + post kernels):
@@ -19,20 +19,22 @@ from tests.gpu_helpers import device_batch, make_frame_batch
 
 pytestmark = pytest.mark.gpu
 
-B, K, A = 256, 9, 9
 FEATS = (32, 64, 64, 512)
 GAMMA_N = 0.99
+SHAPES = [pytest.param((256, 9, 9), id="c2-B256-K9-A9"), pytest.param((1024, 32, 4), id="c5-B1024-K32-A4")]
 
 
-def _engine(seed=0):
+def _engine(shape, seed=0):
     from slimdqn._engine import QNetEngine
 
+    B, K, A = shape
     eng = QNetEngine((84, 84, 4), A, 1 + K, FEATS, "cnn", True, B, gamma_n=GAMMA_N, learning_rate=6.25e-5, adam_eps=1.5e-4)
     eng.init_params(seed)
     return eng
 
 
-def _host_targets(eng, frames, ids, action, reward, terminal):
+def _host_targets(shape, eng, frames, ids, action, reward, terminal):
+    B, K, A = shape
     fr = torch.from_numpy(frames).cuda()
     both = torch.from_numpy(np.concatenate([ids[:, :4], ids[:, 4:]], 0).copy()).cuda()
     q = eng.forward(frames=fr, frame_stride=frames.shape[1], frame_ids=both, n_rows=2 * B).cpu().numpy().astype(np.float64)
@@ -43,13 +45,15 @@ def _host_targets(eng, frames, ids, action, reward, terminal):
     return qv, tg
 
 
-def test_learn_step_is_bitwise_deterministic_and_matches_forward_path():
+@pytest.mark.parametrize("shape", SHAPES)
+def test_learn_step_is_bitwise_deterministic_and_matches_forward_path(shape):
+    B, K, A = shape
     frames, ids, action, reward, terminal, _ = make_frame_batch(B, A, seed=5)
     outs = []
     for _ in range(2):
-        eng = _engine(seed=1)
+        eng = _engine(shape, seed=1)
         batch = device_batch(eng, frames, ids, action, reward, terminal)
-        qv, tg = _host_targets(eng, frames, ids, action, reward.astype(np.float64), terminal.astype(np.float64))
+        qv, tg = _host_targets(shape, eng, frames, ids, action, reward.astype(np.float64), terminal.astype(np.float64))
         pre = eng.loss_on_batch(batch).cpu().numpy().copy()
         losses = eng.learn_on_batch(batch).cpu().numpy().copy()
         torch.cuda.synchronize()
@@ -69,17 +73,19 @@ def test_learn_step_is_bitwise_deterministic_and_matches_forward_path():
         np.testing.assert_array_equal(a, b)
 
 
-def test_several_steps_and_every_intermediate_are_run_to_run_identical():
+@pytest.mark.parametrize("shape", SHAPES)
+def test_several_steps_and_every_intermediate_are_run_to_run_identical(shape):
     """Several back-to-back steps from identical state, three times: parameters, Adam moments and the backward
     intermediates of the last step must be bit-identical.  (This is the test that exposed compiler-renamed dependent
     MFMAs and an LDS hazard in the pipelined K loops: about 1 % of workgroups returned a tile that lacked one MFMA
     pass, invisible to the small-batch oracle comparisons.)"""
+    B, K, A = shape
     frames, ids, action, reward, terminal, _ = make_frame_batch(B, A, seed=13)
     names = ["act/Conv_0", "act/Conv_1", "act/Conv_2", "act/Dense_0", "dz/Dense_0", "dz/Conv_2", "dz/Conv_1", "dz/Conv_0",
              "gw/Conv_0", "gw/Conv_1", "gw/Conv_2"]
     ref = None
     for _ in range(3):
-        eng = _engine(seed=3)
+        eng = _engine(shape, seed=3)
         batch = device_batch(eng, frames, ids, action, reward, terminal)
         for _ in range(4):
             eng.learn_on_batch(batch)
@@ -93,12 +99,14 @@ def test_several_steps_and_every_intermediate_are_run_to_run_identical():
                 assert torch.equal(t, ref[n]), f"{n}: {(t != ref[n]).sum().item()} elements differ between identical runs"
 
 
-def test_batch_permutation_permutes_rows_and_keeps_losses():
+@pytest.mark.parametrize("shape", SHAPES)
+def test_batch_permutation_permutes_rows_and_keeps_losses(shape):
+    B, K, A = shape
     frames, ids, action, reward, terminal, _ = make_frame_batch(B, A, seed=9)
     perm = np.random.default_rng(0).permutation(B)
     res = []
     for order in (np.arange(B), perm):
-        eng = _engine(seed=2)
+        eng = _engine(shape, seed=2)
         batch = device_batch(eng, frames, ids[order], action[order], reward[order], terminal[order])
         losses = eng.learn_on_batch(batch).cpu().numpy().copy()
         res.append((losses, eng.q_values.cpu().numpy().copy(), eng.targets.cpu().numpy().copy(), eng.priorities.cpu().numpy().copy()))

@@ -19,13 +19,28 @@ CONFIGS = [
     pytest.param(((7, 9, 11, 13), 3, 5, 6, True), id="tiny-ln"),
     pytest.param(((16, 20, 5, 24), 2, 3, 5, False), id="tiny-noln"),
     pytest.param(((32, 64, 64, 512), 9, 9, 8, True), id="headline-arch-B8"),
-    # ragged edges of the fused kernels: B not a multiple of the head chain's 4 transitions per workgroup
+    # odd batch: ragged last tiles of every image / row tiling (the head chain runs S = 1 transition per workgroup here)
     pytest.param(((32, 64, 64, 512), 9, 9, 7, True), id="headline-arch-B7-ragged"),
     # configs[4] head shape (K=32, A=4: 132 outputs -> 9 column tiles, padded to 136)
     pytest.param(((32, 64, 64, 512), 32, 4, 12, True), id="c5-head-B12"),
     # 18 actions (full Atari set), B crossing no 64-row tile boundary evenly
     pytest.param(((32, 64, 64, 512), 4, 18, 33, True), id="a18-B33"),
     pytest.param(((32, 64, 64, 512), 3, 6, 10, False), id="headline-arch-noln"),
+]
+
+# Kernel instantiations that only large batches select (BASELINE configs[4]: B = 1024, K = 32, A = 4): the head chain
+# runs S = 2 transitions per workgroup from B = 512 and S = 4 from B = 1024 (net_kernels.hip: `hc_S`), the dense
+# forward / data-gradient / weight-gradient tilings change their split factors, and the image-resident weight
+# gradients group more images per workgroup.  Tiny features keep the CPU oracle at seconds; one case runs the
+# headline widths so that the 64-channel kernels (DenseDgradLN, conv <4, ...>) see B >= 512 against the oracle too.
+LARGE_BATCH = [
+    pytest.param(((8, 8, 8, 16), 3, 4, 512, True), id="tiny-B512-S2"),
+    pytest.param(((8, 8, 8, 16), 32, 4, 1024, True), id="tiny-c5head-B1024-S4"),
+    pytest.param(((8, 8, 8, 16), 9, 9, 515, True), id="tiny-B515-ragged-S2"),
+    pytest.param(((8, 8, 8, 16), 2, 3, 1030, False), id="tiny-noln-B1030-ragged-S4"),
+    pytest.param(((32, 64, 64, 512), 3, 4, 512, True), id="headline-arch-B512-S2"),
+    # BASELINE configs[4] at its full size (the torch oracle needs ~10 s for it on the GPU box's host cores)
+    pytest.param(((32, 64, 64, 512), 32, 4, 1024, True), id="c5-full-size-B1024-K32-A4"),
 ]
 
 
@@ -72,6 +87,50 @@ def test_other_observation_geometries(geo):
         for leaf in o_grads[mod]:
             e = _flat_err(g[mod][leaf], o_grads[mod][leaf].numpy())
             assert e < tol["grad"], f"grad {mod}/{leaf}: rel err {e}"
+
+
+@pytest.mark.parametrize("cfg", LARGE_BATCH)
+def test_large_batch_kernel_variants(cfg):
+    """Forward, targets / losses, first-step gradients of every leaf and one Adam step against the oracle at the batch
+    sizes that switch the kernels to their B >= 512 / B >= 1024 instantiations (isdqn.py:92-109)."""
+    feats, K, A, B, ln = cfg
+    tol = TOL["bf16x3"]
+    oracle, eng, params = make_pair(feats, K, A, B, layer_norm=ln, seed=7)
+    frames, ids, action, reward, terminal, ref = make_frame_batch(B, A, seed=23, n_frames=B + 64)
+    batch = device_batch(eng, frames, ids, action, reward, terminal)
+    with torch.no_grad():
+        all_q = oracle.apply(oracle.params, torch.cat((torch.tensor(ref.state), torch.tensor(ref.next_state)))).numpy()
+    flat_ids = np.concatenate([ids[:, :4], ids[:, 4:]], 0).copy()
+    q = eng.forward(frames=batch._keep[0], frame_stride=frames.shape[1], frame_ids=torch.from_numpy(flat_ids).cuda(), n_rows=2 * B)
+    q = q.cpu().numpy().reshape(2 * B, 1 + K, A)
+    assert np.abs(q - all_q).max() < tol["q"], f"forward max err {np.abs(q - all_q).max()}"
+    o_q, o_t, o_td = oracle.loss_terms(oracle.params, ref)
+    o_grads, _ = oracle.grads(oracle.params, ref)
+    p, st, o_losses = oracle.learn_on_batch(oracle.params, oracle.optimizer_state, ref)
+    grad = torch.zeros_like(eng.params)
+    losses = eng.learn_on_batch(batch, grad_out=grad).cpu().numpy()
+    assert np.abs(eng.targets.cpu().numpy() - o_t.detach().numpy()).max() < tol["q"]
+    assert np.abs(eng.q_values.cpu().numpy() - o_q.detach().numpy()).max() < tol["q"]
+    assert np.abs(losses - o_losses).max() < tol["loss"] * max(1.0, np.abs(o_losses).max())
+    pri = eng.priorities.cpu().numpy()
+    exp = np.sqrt(o_td.detach().numpy().mean(1) + 1e-10)
+    assert np.abs(pri - exp).max() < 10 * tol["q"] * max(1.0, exp.max())
+    # Gradients: with 10^5 .. 10^7 ReLU inputs per batch a handful lie within the forward's 1e-5 of zero, and each such
+    # element whose mask differs from the oracle's moves single gradient entries by O(1/B) of the leaf's maximum
+    # (scripts/r2/diag_grad.py: one element of dz/Conv_1 in 248k at B = 32).  The Euclidean error is insensitive to
+    # those isolated flips, the max-norm bound only has to exclude a wrong tile / a missing image.
+    g = eng.internal_to_flax_grads(grad)
+    for mod in o_grads:
+        for leaf in o_grads[mod]:
+            a, b = np.asarray(g[mod][leaf], np.float64), o_grads[mod][leaf].numpy().astype(np.float64)
+            l2 = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+            assert l2 < tol["grad"], f"grad {mod}/{leaf}: relative L2 err {l2}"
+            assert _flat_err(a, b) < 10 * tol["grad"], f"grad {mod}/{leaf}: rel max err {_flat_err(a, b)}"
+    got = eng.export_flax()
+    for mod in p:
+        for leaf in p[mod]:
+            d = np.abs(got[mod][leaf] - p[mod][leaf].numpy()).max()
+            assert d < 1e-3 * 3 * max(tol["grad"] * 50, 0.02) + tol["param"], f"param {mod}/{leaf}: {d}"
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
