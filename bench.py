@@ -13,9 +13,15 @@ Workloads (BASELINE.json configs):
   c3 (configs[2]):          same + prioritized replay (sum tree) + n=3 + priority writeback
   c5 (configs[4]):          Breakout-shaped A=4, K=32, B=1024
 
-N > 1: one process per GPU (torchrun), independent replicas (own seed, own replay, own parameters) --
-the path shards embarrassingly, no data-path collective; RCCL carries only the timing
-reduction.  value = N * K / max-over-ranks(time).  Prints ONE JSON line on rank 0.
+N > 1: one process per GPU, independent replicas (own seed, own replay, own parameters) -- the path shards
+embarrassingly, no data-path collective; RCCL carries only the timing reduction.  Started as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the driver does that) the ranks come from
+the environment; started as plain `python bench.py --gpus N` the parent spawns exactly that torchrun command as a child
+BEFORE touching any GPU and relays its output.  value = N * K / max-over-ranks(time).  ONE JSON line on rank 0.
+
+The timed region is EXACTLY --steps steps behind EXACTLY --warmup warm-up steps (the steps captured per hipGraph are
+chosen to divide both); an untimed settle phase in front of them (reported as `settle_steps`) takes a fresh process
+to its steady state, and a separate pass brackets single graph replays with HIP events for median / p10 / p90.
 """
 import argparse
 import json
@@ -55,27 +61,30 @@ def algorithmic_flops_per_step(B, K, A):
 
 
 def measured_traffic(workload, precision):
-    """HBM bytes per step from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
-    correction applied; collected by hand with the recipe in profiles/round1/README.md and committed as JSON): counters
-    cannot be read from inside this process, so this is the last committed measurement for the same workload and
-    precision, or null when there is none."""
+    """HBM bytes per step from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of THIS
+    script's graphed workload, step kernels only, gfx950 correction applied: scripts/pmc_traffic.py; committed as JSON under
+    profiles/).  Counters cannot be read from inside this process, so the line carries the newest committed measurement
+    for the same workload and precision together with where it came from -- or null."""
     import glob
-
     import re
 
     def version(path):  # (round, v) as numbers: "v10" is newer than "v9"
         m = re.search(r"round(\d+).*_v(\d+)\.json$", path.replace(os.sep, "/"))
         return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
 
-    best = None
+    best, best_path = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"{workload}_hbm_traffic_*.json")), key=version):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
         if d.get("workload") == workload and d.get("precision") == precision:
-            best = d
-    return None if best is None else float(best["hbm_bytes_per_step_corrected"])
+            best, best_path = d, f
+    if best is None:
+        return None, None
+    src = {"file": os.path.relpath(best_path, ROOT), "build": best.get("build"), "collected_with": best.get("command"),
+           "note": "not measured by this run"}
+    return float(best["hbm_bytes_per_step_corrected"]), src
 
 
 class Replica:
@@ -121,9 +130,10 @@ class Replica:
         return batch
 
 
-def cpu_baseline(workload, seconds_budget=20.0):
-    """The oracle (torch-CPU fp32 restatement of the reference path: numpy PCG64 sampler (+ sum tree), uint8 stack
-    gather, forward/backward/Adam) timed on this box's host cores on a BOUNDED sample of the same workload."""
+def cpu_baseline(workload, seconds_budget=20.0, capacity=1_000_000):
+    """The oracle (torch-CPU fp32 restatement of the reference path: numpy PCG64 sampler (+ float64 sum tree), uint8
+    stack gather out of a `capacity`-element replay, forward / backward / Adam) timed on this box's host cores on a
+    BOUNDED sample of the same workload: half of the budget with every core the process may use, half with one thread."""
     import numpy as np
     import torch
     from oracle.isdqn import iSDQN as Oracle
@@ -132,42 +142,57 @@ def cpu_baseline(workload, seconds_budget=20.0):
 
     w = WORKLOADS[workload]
     try:
-        cores = len(os.sched_getaffinity(0))
+        usable = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("ISDQN_CPU_BASELINE_THREADS", "16"))))  # a 1-GPU box's CPU share is 16 cores
-    torch.set_num_threads(cores)
-    cap = 1024  # bounded replay: the CPU step cost does not depend on the capacity (sampling is O(B log C))
+        usable = os.cpu_count() or 1
+    cap = int(capacity)
     rng = np.random.default_rng(0)
     sampler = OP(0, cap) if w["prioritized"] else OU(0)
     rb = ORB(sampler, w["B"], cap, stack_size=4, update_horizon=w["n"], gamma=0.99)
-    frames = rng.integers(0, 256, (cap + 8, 84, 84), dtype=np.uint8)
-    for i in range(cap):  # direct fill of the oracle's memory (one long stream), like prefill_synthetic
-        st = np.moveaxis(frames[i : i + 4], 0, -1)
-        nx = np.moveaxis(frames[i + w["n"] : i + w["n"] + 4], 0, -1)
-        rb._memory[i] = ReplayElement(st, int(rng.integers(0, w["n_actions"])), float(rng.choice([-1.0, 0.0, 1.0])), nx, False)
-        if w["prioritized"]:
-            sampler.add(i, float(rng.uniform(0.1, 2.0)))
-        else:
-            sampler.add(i)
+    # one long synthetic stream like prefill_synthetic: element i = frames i..i+3 / i+n..i+n+3.  The stacks are VIEWS of the
+    # frame store (7 GB at 1e6 elements; the reference would hold 56 GB of copies), copied at sampling time like the reference
+    frames = np.empty((cap + 8, 84, 84), np.uint8)
+    for s0 in range(0, cap + 8, 65536):
+        e0 = min(cap + 8, s0 + 65536)
+        frames[s0:e0] = rng.integers(0, 256, (e0 - s0, 84, 84), dtype=np.uint8)
+    actions = rng.integers(0, w["n_actions"], cap)
+    rewards = rng.choice([-1.0, 0.0, 1.0], size=cap, p=[0.05, 0.9, 0.05])
+    mem = rb._memory
+    n = w["n"]
+    for i in range(cap):
+        mem[i] = ReplayElement(np.moveaxis(frames[i : i + 4], 0, -1), int(actions[i]), float(rewards[i]),
+                               np.moveaxis(frames[i + n : i + n + 4], 0, -1), False)
+    sampler._index_to_key = list(range(cap))
+    sampler._key_to_index = {i: i for i in range(cap)}
+    if w["prioritized"]:
+        sampler._sum_tree.set(np.arange(cap, dtype=np.int32), rng.uniform(0.1, 2.0, cap))
     rb.add_count = cap
     agent = Oracle(0, (84, 84, 4), w["n_actions"], w["K"], list(FEATURES), True, False, "cnn", 6.25e-5, 0.99, w["n"], 1, 8000, adam_eps=1.5e-4)
 
     def one():
         batch = rb.sample()
         agent.params, agent.optimizer_state, _ = agent.learn_on_batch(agent.params, agent.optimizer_state, batch)
+        if w["prioritized"]:
+            pass  # (the oracle trainer has no write-back wiring either: reference SURVEY 8a P2)
 
-    one()  # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        one()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 50:
-            break
-    return {"value": n / el, "unit": "gradient-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of the oracle (torch-CPU fp32 restatement) at B={w['B']}, K={w['K']}, replay of {cap} elements, {cores} threads"}
+    def timed(threads, budget, max_steps):
+        torch.set_num_threads(threads)
+        one()  # warm-up
+        t0 = time.perf_counter()
+        k = 0
+        while True:
+            one()
+            k += 1
+            el = time.perf_counter() - t0
+            if el > budget or k >= max_steps:
+                return k / el, k
+
+    all_rate, all_n = timed(usable, seconds_budget / 2, 50)
+    one_rate, one_n = timed(1, seconds_budget / 2, 10)
+    return {"value": all_rate, "unit": "gradient-steps/s", "cores": usable, "kind": "port",
+            "one_thread_value": one_rate, "os_cpu_count": os.cpu_count(),
+            "sample": f"{all_n} steps with {usable} threads and {one_n} steps with 1 thread of the oracle (torch-CPU fp32 restatement) at "
+                      f"B={w['B']}, K={w['K']}, replay of {cap} elements (os.cpu_count() = {os.cpu_count()}, usable = {usable})"}
 
 
 def max_over_ranks(seconds, device):
@@ -186,50 +211,85 @@ def aggregate_value(world, steps, elapsed_max):
     return world * steps / elapsed_max
 
 
+def spawn_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child torchrun job.  Runs BEFORE this process
+    has imported torch or touched a GPU (the parent never does), and hands the child's exit status back."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def steps_per_graph(steps: int, warmup: int, limit: int) -> int:
+    """Largest S <= limit dividing both the timed and the warm-up step count (a graph replays S steps at a time)."""
+    import math
+
+    g = math.gcd(steps, warmup) if warmup > 0 else steps
+    return max(d for d in range(1, max(1, limit) + 1) if g % d == 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # ~1.2 s of timed work (300-step runs scatter by +-15 %), behind ~1.2 s of warm-up: the first process on a fresh
-    # box reads 5-8 % low for its first second (3142 vs 3400 steps/s with 100 warm-up steps, 3403 with 6000), and a
-    # training run lasts hours, so the steady state is the number
+    # defaults: ~1.2 s of timed work (300-step runs scatter by +-15 %) behind ~1.2 s of warm-up
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=4000)
+    ap.add_argument("--settle", type=int, default=-1, help="untimed steps in front of the warm-up (default: up to 2000 so that warm-up + settle >= 2000)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--capacity", type=int, default=1_000_000)
-    ap.add_argument("--graph", type=int, default=8, help="steps captured per hipGraph (0 = eager launches)")
+    ap.add_argument("--graph", type=int, default=8, help="most steps captured per hipGraph (0 = eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-capacity", type=int, default=1_000_000)
+    ap.add_argument("--replay-stats", type=int, default=200, help="graph replays timed one by one after the run (0 = skip)")
     args = ap.parse_args()
+    assert args.steps >= 1 and args.warmup >= 0 and args.gpus >= 1
 
-    import torch
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a wrong n_gpus",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+
+    import torch
+
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
     w = WORKLOADS[args.workload]
 
     rep = Replica(args.workload, args.capacity, args.precision, seed=rank, device=device)
     S = 1
     if args.graph > 0:
+        S = steps_per_graph(args.steps, args.warmup, args.graph)
         try:
-            rep.enable_graph(args.graph)
-            S = args.graph
+            rep.enable_graph(S)
         except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
-            rep.graphed = None
-    args.steps = max(S, args.steps // S * S)  # a graph replays S steps at a time
-    args.warmup = max(S, args.warmup // S * S)
+            rep.graphed, S = None, 1
     one = (lambda: rep.graphed.run()) if rep.graphed is not None else rep.step
+    settle = args.settle if args.settle >= 0 else max(0, 2000 - args.warmup)
+    settle = (settle + S - 1) // S * S
+    for _ in range(settle // S):
+        one()
     for _ in range(args.warmup // S):
         one()
     torch.cuda.synchronize()
@@ -255,11 +315,26 @@ def main():
 
     elapsed_max = max_over_ranks(elapsed, device)
 
+    # distribution over single replays (own pass, outside the timed region: every replay bracketed by its own events)
+    stats = None
+    if rank == 0 and args.replay_stats > 0:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.replay_stats)]
+        for a, b in evs:
+            a.record()
+            one()
+            b.record()
+        torch.cuda.synchronize()
+        per_step = sorted(a.elapsed_time(b) / S for a, b in evs)
+        q = lambda f: per_step[min(len(per_step) - 1, int(f * len(per_step)))]
+        stats = {"replays": len(per_step), "steps_per_replay": S, "ms_per_step_median": q(0.5), "ms_per_step_p10": q(0.1),
+                 "ms_per_step_p90": q(0.9), "note": "each replay bracketed by its own HIP events (adds ~6 us per replay); not the timed region"}
+
     if rank == 0:
         dev_ms_avg = ev0.elapsed_time(ev1) / args.steps
         bytes_step = algorithmic_bytes_per_step(w["B"], w["K"], w["n_actions"], w["prioritized"])
         flops_step = algorithmic_flops_per_step(w["B"], w["K"], w["n_actions"])
         achieved = bytes_step / (dev_ms_avg * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(args.workload, args.precision)
         out = {
             "metric": "gradient-steps/sec (batch=256, K=9, 84x84x4)" if args.workload != "c5" else "gradient-steps/sec (batch=1024, K=32, 84x84x4)",
             "value": aggregate_value(world, args.steps, elapsed_max),
@@ -267,25 +342,29 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settle,
             "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "bf16x3 (split-bf16 MFMA operands hi+lo, fp32 accumulate)" if args.precision == "bf16x3" else "bf16 (single pass, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": w["desc"], "replay_capacity": args.capacity, "precision": args.precision,
                        "launch": f"hipGraph x{S} steps" if rep.graphed is not None else "eager", "replicas": world, "parallelism": f"independent-seed replicas x{world}"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.workload, args.precision),
+                "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "replay-sample -> Bellman-update step (all launches of one step; HIP-event time per step)",
                 "algorithmic_bytes_per_step": bytes_step, "device_ms_per_step_avg": dev_ms_avg,
                 "host_issue_ms_per_step": t_issue / args.steps * 1e3,
                 "mfma_util_vs_2.5PF": flops_step / (dev_ms_avg * 1e-3) / 2.5e15,
             },
         }
+        if stats is not None:
+            out["replay_stats"] = stats
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+            del rep  # (frees nothing the baseline needs; keeps host memory for the 7 GB oracle frame store)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_capacity)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -21,6 +21,9 @@ from slimdqn.sample_collection.samplers import PrioritizedSamplingDistribution, 
 
 
 def run(argvs=sys.argv[1:], root=None):
+    from experiments.base import dist as replicas
+
+    replicas.init_from_env()  # one process per GPU: picks this rank's device before the first GPU call (no-op alone)
     p = prepare_logs("atari", "isdqn", argvs, root=root)
     rng = np.random.default_rng(p["seed"])
     q_seed, train_seed = (int(s) for s in rng.integers(0, 2**31 - 1, size=2))
@@ -68,24 +71,20 @@ def run(argvs=sys.argv[1:], root=None):
     )
     if p["prioritized"]:
         _wire_prioritized(agent, rb)
-    return train(np.random.default_rng(train_seed), p, agent, env, rb)
+    out = train(np.random.default_rng(train_seed), p, agent, env, rb)
+    replicas.finalize()
+    return out
 
 
 def _wire_prioritized(agent, rb):
     """Trainer wiring the reference does not have: new elements enter with the
-    largest priority seen so far (Dopamine's convention), sampled elements get sqrt(mean_k td) written back."""
-    tree = rb._sampling_distribution._sum_tree
+    largest priority seen so far (Dopamine's convention), sampled elements get sqrt(mean_k td) written back.
+    Neither costs a read-back: the maximum is resolved on the device when the staged leaf writes are flushed
+    (samplers.py MAX_PRIORITY), the write-back is part of the captured step (networks/isdqn.py)."""
+    sampler = rb._sampling_distribution
     plain_add = rb.add
-    rb.add = lambda transition, **kw: plain_add(transition, priority=kw.get("priority", tree.max_recorded_priority))
-    plain_update = agent.update_online_params
-
-    def update_online_params(step, replay_buffer):
-        if step % agent.data_to_update == 0:
-            batch = replay_buffer.sample()
-            agent.params, agent.optimizer_state, _ = agent.learn_on_batch(agent.params, agent.optimizer_state, batch)
-            replay_buffer.update_device(batch, agent._engine.priorities)
-
-    agent.update_online_params = update_online_params
+    rb.add = lambda transition, **kw: plain_add(transition, priority=kw.get("priority", sampler.MAX_PRIORITY))
+    agent.priority_writeback = True
 
 
 if __name__ == "__main__":

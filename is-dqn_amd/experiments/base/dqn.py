@@ -9,26 +9,21 @@ the model is kept when the epoch's average return is the best so far.
 One process drives one GPU; with torch.distributed initialised (one seed/game per rank, launched by
 experiments/launch.py) the only communication is an all_gather of a few per-epoch scalars.
 """
+import os
+import time
+
 import numpy as np
 
+from experiments.base import dist as replicas
 from experiments.base.utils import save_data
 from slimdqn.sample_collection.utils import collect_single_sample, linear_schedule
+
+EPOCH_FIELDS = ("avg_return", "avg_length_episode", "n_training_steps", "env_steps_per_s")
 
 
 def _gather_epoch_metrics(metrics: np.ndarray):
     """all_gather of the per-epoch metric vector over RCCL (xGMI); identity when not distributed."""
-    try:
-        import torch
-        import torch.distributed as dist
-    except ImportError:  # pragma: no cover
-        return metrics[None]
-    if not (dist.is_available() and dist.is_initialized()):
-        return metrics[None]
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    mine = torch.tensor(metrics, dtype=torch.float32, device=dev)
-    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, mine)
-    return torch.stack(out).cpu().numpy()
+    return replicas.gather_metrics(metrics)
 
 
 def train(key, p: dict, agent, env, rb):
@@ -43,6 +38,7 @@ def train(key, p: dict, agent, env, rb):
 
     for idx_epoch in range(p["n_epochs"]):
         steps_in_epoch, has_reset = 0, False
+        t_epoch = time.perf_counter()
         while steps_in_epoch < p["n_training_steps_per_epoch"] or not has_reset:
             reward, has_reset = collect_single_sample(rng, env, agent, rb, p, epsilon_schedule, n_training_steps)
             steps_in_epoch += 1
@@ -63,7 +59,8 @@ def train(key, p: dict, agent, env, rb):
         print(f"\nEpoch {idx_epoch}: Return {avg_return} averaged on {len(lengths[idx_epoch])} episodes.\n", flush=True)
         p["wandb"].log({"epoch": idx_epoch, "n_training_steps": n_training_steps, "avg_return": avg_return,
                         "avg_length_episode": avg_length})
-        gathered.append(_gather_epoch_metrics(np.asarray([avg_return, avg_length, n_training_steps], np.float32)))
+        rate = steps_in_epoch / max(time.perf_counter() - t_epoch, 1e-9)
+        gathered.append(_gather_epoch_metrics(np.asarray([avg_return, avg_length, n_training_steps, rate], np.float32)))
 
         model = None
         if avg_return > best_avg_return:
@@ -73,4 +70,7 @@ def train(key, p: dict, agent, env, rb):
             returns.append([0])
             lengths.append([0])
         save_data(p, returns, lengths, model)
+        if os.environ.get("WORLD_SIZE", "1") != "1":  # rank 0: every replica's per-epoch metrics in one file
+            replicas.write_gathered(os.path.join(os.path.dirname(os.path.dirname(p["save_path"])), "gathered_metrics.json"),
+                                    gathered, EPOCH_FIELDS)
     return gathered

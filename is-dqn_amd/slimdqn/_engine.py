@@ -34,11 +34,12 @@ class QNetEngine:
         learning_rate: float = 1e-3,
         adam_eps: float = 1e-8,
         precision: str = "bf16x3",
-        device: str = "cuda:0",
+        device: str | None = None,
     ):
         _hip.require_gpu()
         self.lib = _hip.lib()
-        self.device = torch.device(device)
+        self.device = _hip.resolve_device(device)
+        _hip.bind_device(self.device)
         cfg = _hip.NetConfig()
         if architecture_type == "cnn":
             cfg.arch = _hip.ARCH_CNN
@@ -233,7 +234,7 @@ class QNetEngine:
         _hip.check(
             self.lib.isdqn_net_forward(
                 ctypes.byref(self.cfg), _hip.ptr(p), _hip.ptr(frames), int(frame_stride), _hip.ptr(frame_ids),
-                _hip.ptr(obs), int(n_rows), _hip.ptr(q), _hip.ptr(self.workspace), _hip.stream_ptr(),
+                _hip.ptr(obs), int(n_rows), _hip.ptr(q), _hip.ptr(self.workspace), _hip.stream_ptr(self.device),
             ),
             "isdqn_net_forward",
         )
@@ -244,7 +245,7 @@ class QNetEngine:
         args = [
             ctypes.byref(self.cfg), _hip.ptr(self.params), _hip.ptr(self.adam_m), _hip.ptr(self.adam_v),
             _hip.ptr(self.adam_count), ctypes.byref(batch), _hip.ptr(self.losses), _hip.ptr(self.losses_accum), _hip.ptr(self.q_values),
-            _hip.ptr(self.targets), _hip.ptr(self.priorities), _hip.ptr(self.workspace), _hip.stream_ptr(),
+            _hip.ptr(self.targets), _hip.ptr(self.priorities), _hip.ptr(self.workspace), _hip.stream_ptr(self.device),
         ]
         if grad_out is None:
             rc = self.lib.isdqn_net_learn_on_batch(*args)
@@ -258,7 +259,7 @@ class QNetEngine:
         _hip.check(
             self.lib.isdqn_net_loss_on_batch(
                 ctypes.byref(self.cfg), _hip.ptr(p), ctypes.byref(batch), _hip.ptr(self.losses),
-                _hip.ptr(self.q_values), _hip.ptr(self.targets), _hip.ptr(self.workspace), _hip.stream_ptr(),
+                _hip.ptr(self.q_values), _hip.ptr(self.targets), _hip.ptr(self.workspace), _hip.stream_ptr(self.device),
             ),
             "isdqn_net_loss_on_batch",
         )
@@ -266,14 +267,14 @@ class QNetEngine:
 
     def shift_params(self, params=None) -> None:
         p = self.params if params is None else params
-        _hip.check(self.lib.isdqn_net_shift_params(ctypes.byref(self.cfg), _hip.ptr(p), _hip.stream_ptr()))
+        _hip.check(self.lib.isdqn_net_shift_params(ctypes.byref(self.cfg), _hip.ptr(p), _hip.stream_ptr(self.device)))
 
     def best_action(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, idx_network: int, params=None) -> torch.Tensor:
         p = self.params if params is None else params
         _hip.check(
             self.lib.isdqn_net_best_action(
                 ctypes.byref(self.cfg), _hip.ptr(p), _hip.ptr(frames), int(frame_stride), _hip.ptr(frame_ids),
-                _hip.ptr(obs), int(idx_network), _hip.ptr(self.action_out), _hip.ptr(self.workspace), _hip.stream_ptr(),
+                _hip.ptr(obs), int(idx_network), _hip.ptr(self.action_out), _hip.ptr(self.workspace), _hip.stream_ptr(self.device),
             ),
             "isdqn_net_best_action",
         )

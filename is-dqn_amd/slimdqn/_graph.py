@@ -16,8 +16,11 @@ from slimdqn import _hip
 
 
 class GraphedUpdate:
-    def __init__(self, rb, eng, prioritized: bool, steps_per_graph: int = 8):
+    def __init__(self, rb, eng, prioritized: bool, steps_per_graph: int = 8, writeback: bool | None = None):
+        """``prioritized``: the sampler is a sum tree (the query is part of the graph); ``writeback``: sqrt(mean_k td) of
+        every step goes back into the tree (default: whenever prioritized)."""
         self.rb, self.eng, self.prioritized, self.S = rb, eng, prioritized, steps_per_graph
+        self.writeback = prioritized if writeback is None else (writeback and prioritized)
         dev, B, s2 = eng.device, eng.batch_size, 2 * rb._stack_size
         self.B = B
         rb._flush()
@@ -52,7 +55,7 @@ class GraphedUpdate:
                 _hip.ptr(rb._d_elem_frames), _hip.ptr(rb._d_elem_action), _hip.ptr(rb._d_elem_reward),
                 _hip.ptr(rb._d_elem_terminal), rb._stack_size, _hip.ptr(rb._d_index_to_slot), _hip.ptr(idx), n_rows,
                 _hip.ptr(self.frame_ids[slot]), _hip.ptr(self.action[slot]), _hip.ptr(self.reward[slot]),
-                _hip.ptr(self.terminal[slot]), _hip.stream_ptr(),
+                _hip.ptr(self.terminal[slot]), _hip.stream_ptr(self.eng.device),
             ),
             "isdqn_replay_gather_rows",
         )
@@ -66,7 +69,8 @@ class GraphedUpdate:
                 tree.query_device(self.block[s], out=self.indices, unit=True)
                 self._gather(self.indices, self.B, 0)
                 eng.learn_on_batch(self.batches[0])
-                rb._sampling_distribution.update_device(self.indices, eng.priorities)
+                if self.writeback:
+                    rb._sampling_distribution.update_device(self.indices, eng.priorities)
         else:
             self._gather(self.block, self.S * self.B, 0)  # rows of all S steps: the [S][B] buffers are contiguous
             for s in range(self.S):
@@ -77,7 +81,10 @@ class GraphedUpdate:
         side = torch.cuda.Stream(self.eng.device)
         side.wait_stream(torch.cuda.current_stream(self.eng.device))
         state = [t.clone() for t in (self.eng.params, self.eng.adam_m, self.eng.adam_v, self.eng.adam_count, self.eng.losses_accum)]
-        tree_nodes = self.rb._sampling_distribution._sum_tree._nodes_dev.clone() if self.prioritized else None
+        # (prioritized: the warm-up also writes priorities back -- with the zero-filled draw block -- so the whole tree
+        # state is saved: nodes, max_recorded_priority, which every later add() reads, and the latched status word)
+        tree = self.rb._sampling_distribution._sum_tree if self.prioritized else None
+        tree_state = [t.clone() for t in (tree._nodes_dev, tree._max_dev, tree._status)] if tree is not None else None
         with torch.cuda.stream(side):
             self._steps()
         torch.cuda.current_stream(self.eng.device).wait_stream(side)
@@ -88,8 +95,9 @@ class GraphedUpdate:
         # the warm-up steps must not count: restore the training state
         for dst, src in zip((self.eng.params, self.eng.adam_m, self.eng.adam_v, self.eng.adam_count, self.eng.losses_accum), state):
             dst.copy_(src)
-        if tree_nodes is not None:
-            self.rb._sampling_distribution._sum_tree._nodes_dev.copy_(tree_nodes)
+        if tree is not None:
+            for dst, src in zip((tree._nodes_dev, tree._max_dev, tree._status), tree_state):
+                dst.copy_(src)
         self.graph = g
 
     def run(self) -> None:

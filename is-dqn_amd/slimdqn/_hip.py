@@ -174,10 +174,47 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
-def stream_ptr() -> int:
+def default_device():
+    """The GPU this process drives.  One process per GPU: under torchrun / experiments/launch.py the rank's
+    LOCAL_RANK selects it (a launcher that sets HIP_VISIBLE_DEVICES per child leaves exactly one visible device, cuda:0);
+    a plain single-process run gets cuda:0."""
     import torch
 
-    return torch.cuda.current_stream().cuda_stream
+    idx = int(os.environ.get("ISDQN_DEVICE_INDEX", os.environ.get("LOCAL_RANK", "0")))
+    n = torch.cuda.device_count()
+    if n and idx >= n:
+        idx = 0  # the launcher narrowed HIP_VISIBLE_DEVICES to this rank's GPU
+    return torch.device("cuda", idx)
+
+
+def resolve_device(device):
+    import torch
+
+    dev = default_device() if device is None else torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return dev
+
+
+def bind_device(device) -> None:
+    """Make `device` the calling thread's current HIP device: the library launches on the current device (per-device
+    side stream, function attributes), so an object on cuda:k must only ever be driven with cuda:k current."""
+    import torch
+
+    if device.type == "cuda" and torch.cuda.is_available() and torch.cuda.current_device() != device.index:
+        torch.cuda.set_device(device)
+
+
+def stream_ptr(device=None) -> int:
+    """HIP stream the C-ABI call is enqueued on: torch's current stream OF THE OBJECT'S DEVICE.  Fails loudly when the
+    thread's current device is another one (kernels would be launched on device A against pointers of device B)."""
+    import torch
+
+    if device is not None and device.type == "cuda" and device.index is not None and device.index != torch.cuda.current_device():
+        raise RuntimeError(
+            f"isdqn_hip: object lives on {device} but the calling thread's current device is cuda:{torch.cuda.current_device()}; "
+            f"one process drives one GPU -- call torch.cuda.set_device({device.index}) (experiments/launch.py does)")
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def require_gpu():

@@ -63,7 +63,8 @@ class iSDQN:
         adam_eps: float = 1e-8,
         batch_size: int = 32,
         precision: str = "bf16x3",
-        device: str = "cuda:0",
+        device: str | None = None,
+        use_graph: bool = True,
     ):
         if batch_norm:
             raise NotImplementedError("BatchNorm variants are outside the hot-path scope (SURVEY.md section 8)")
@@ -86,6 +87,11 @@ class iSDQN:
         self._seed = int(key) if not isinstance(key, torch.Generator) else int(key.initial_seed())
         self._action_rng = np.random.default_rng(self._seed + 1)
         self._engine = None
+        # update_online_params on a device replay runs as a captured single step (hipGraph: one launch instead of ~25
+        # kernel launches on two streams); priority_writeback adds the sum-tree write-back of the step's TD errors
+        self.use_graph = bool(use_graph)
+        self.priority_writeback = False
+        self._graphed = None
         self._make_engine(batch_size, init=True)
         self.cumulated_losses = np.zeros(self.n_bellman_iterations)
 
@@ -106,6 +112,7 @@ class iSDQN:
             eng.adam_count.copy_(old.adam_count)
             eng.losses_accum.copy_(old.losses_accum)
         self._engine = eng
+        self._graphed = None  # captured against the old engine's buffers
         self.params = DeviceParams(eng, eng.params)
         self.optimizer_state = {"count": eng.adam_count, "mu": eng.adam_m, "nu": eng.adam_v}
 
@@ -147,7 +154,7 @@ class iSDQN:
         planes = torch.empty(2 * B * stack, h * w, dtype=torch.uint8, device=dev)
         ids = torch.empty(B, 2 * stack, dtype=torch.int32, device=dev)
         _hip.check(
-            eng.lib.isdqn_replay_deinterleave(_hip.ptr(st), _hip.ptr(nx), h, w, stack, B, _hip.ptr(planes), _hip.ptr(ids), _hip.stream_ptr())
+            eng.lib.isdqn_replay_deinterleave(_hip.ptr(st), _hip.ptr(nx), h, w, stack, B, _hip.ptr(planes), _hip.ptr(ids), _hip.stream_ptr(dev))
         )
         return eng.make_batch(frames=planes, frame_stride=h * w, frame_ids=ids, action=action, reward=reward, terminal=terminal)
 
@@ -156,10 +163,32 @@ class iSDQN:
         return int(samples.action.shape[0])
 
     # ------------------------------------------------------------------ isdqn.py:55-80
+    def _graphed_update(self, replay_buffer):
+        """The captured sample -> learn -> [write-back] step for this (replay, engine) pair, or None when the replay is
+        not the device replay of this GPU (reference-layout buffers take the eager path)."""
+        if not self.use_graph or not hasattr(replay_buffer, "_d_elem_frames") or getattr(replay_buffer, "_lib", None) is None:
+            return None
+        if self.architecture_type != "cnn" or replay_buffer.add_count == 0:
+            return None
+        eng = self._engine_for(replay_buffer._batch_size)
+        prioritized = hasattr(replay_buffer._sampling_distribution, "_tree")
+        g = self._graphed
+        if g is None or g.rb is not replay_buffer or g.eng is not eng or g.writeback != (self.priority_writeback and prioritized):
+            from slimdqn._graph import GraphedUpdate
+
+            g = self._graphed = GraphedUpdate(replay_buffer, eng, prioritized, steps_per_graph=1, writeback=self.priority_writeback)
+        return g
+
     def update_online_params(self, step: int, replay_buffer):
         if step % self.data_to_update == 0:
+            g = self._graphed_update(replay_buffer)
+            if g is not None:
+                g.run()  # same draws, same kernels, same bits as the eager branch below (tests/test_gpu_graphed_update.py)
+                return
             batch_samples = replay_buffer.sample()
             self.params, self.optimizer_state, _ = self.learn_on_batch(self.params, self.optimizer_state, batch_samples)
+            if self.priority_writeback and hasattr(replay_buffer, "update_device"):
+                replay_buffer.update_device(batch_samples, self._engine.priorities)
             # `cumulated_losses += losses` (isdqn.py:62) happens on the device inside the step
 
     def update_target_params(self, step: int):

@@ -83,7 +83,7 @@ class DeviceBatch:
             _hip.check(
                 rb._lib.isdqn_replay_materialize(
                     _hip.ptr(self.frames), self.frame_stride, rb._h, rb._w, rb._stack_size, _hip.ptr(self.frame_ids),
-                    B, _hip.ptr(st), _hip.ptr(nx), _hip.stream_ptr(),
+                    B, _hip.ptr(st), _hip.ptr(nx), _hip.stream_ptr(rb.device),
                 ),
                 "isdqn_replay_materialize",
             )
@@ -153,11 +153,12 @@ class ReplayBuffer:
         checkpoint_duration: int = 4,
         compress: bool = True,
         clipping: callable = None,
-        device: str = "cuda:0",
+        device: str | None = None,
     ):
-        self.device = torch.device(device)
+        self.device = _hip.resolve_device(device)
         if self.device.type == "cuda":
             _hip.require_gpu()
+            _hip.bind_device(self.device)
             self._lib = _hip.lib()
         else:
             # host-logic testing only: storage on the CPU, no kernels -- sampling raises (there is no CPU fallback)
@@ -234,9 +235,12 @@ class ReplayBuffer:
             self._free.append(slot)
 
     def _flush(self) -> None:
-        """Upload pending frames / table rows (plumbing copies; the hot path never waits on them)."""
+        """Upload pending frames / table rows / staged leaf priorities (plumbing copies; the hot path never waits on them)."""
         if self._frames is None:
             return
+        flush_sampler = getattr(self._sampling_distribution, "flush", None)
+        if flush_sampler is not None:
+            flush_sampler()
         if self._pending_frames:
             slots = np.fromiter(self._pending_frames.keys(), dtype=np.int64, count=len(self._pending_frames))
             data = np.stack(list(self._pending_frames.values()))
@@ -365,7 +369,7 @@ class ReplayBuffer:
             self._lib.isdqn_replay_gather_rows(
                 _hip.ptr(self._d_elem_frames), _hip.ptr(self._d_elem_action), _hip.ptr(self._d_elem_reward),
                 _hip.ptr(self._d_elem_terminal), self._stack_size, _hip.ptr(self._d_index_to_slot), _hip.ptr(indices),
-                B, _hip.ptr(ids), _hip.ptr(action), _hip.ptr(reward), _hip.ptr(terminal), _hip.stream_ptr(),
+                B, _hip.ptr(ids), _hip.ptr(action), _hip.ptr(reward), _hip.ptr(terminal), _hip.stream_ptr(self.device),
             ),
             "isdqn_replay_gather_rows",
         )

@@ -61,11 +61,11 @@ class _Uploader:
 class UniformSamplingDistribution:
     """samplers.py:13-49."""
 
-    def __init__(self, seed: int, device: str = "cuda:0") -> None:
+    def __init__(self, seed: int, device: str | None = None) -> None:
         self._rng_key = np.random.default_rng(seed)
         self._key_to_index = {}
         self._index_to_key = []
-        self.device = torch.device(device)
+        self.device = _hip.resolve_device(device)
         self._uploader = None
         self._pf = None        # prefetched draws: dict(host, dev, next, n, size, length, state)
         self._last_len = -1
@@ -165,7 +165,7 @@ class UniformSamplingDistribution:
 class PrioritizedSamplingDistribution(UniformSamplingDistribution):
     """samplers.py:52-116 with the sum tree resident on the GPU."""
 
-    def __init__(self, seed: int, max_capacity: int, priority_exponent: float = 1.0, device: str = "cuda:0") -> None:
+    def __init__(self, seed: int, max_capacity: int, priority_exponent: float = 1.0, device: str | None = None) -> None:
         self._max_capacity = max_capacity
         self._priority_exponent = priority_exponent
         # The buffer briefly holds max_capacity + 1 keys (add, then evict: replay_buffer.py:190-196), so leaf
@@ -173,36 +173,66 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         # (then sum_tree.py:33 raises IndexError at the first eviction).  One spare leaf in that case only: the
         # extra level has a zero right subtree, so every query descends exactly as in the smaller tree.
         leaves = self._max_capacity + 1 if (self._max_capacity & (self._max_capacity - 1)) == 0 else self._max_capacity
-        self._sum_tree = sum_tree.SumTree(leaves, device=device)
-        super().__init__(seed=seed, device=device)
+        self._tree = sum_tree.SumTree(leaves, device=device)
+        super().__init__(seed=seed, device=self._tree.device)
+        # leaf writes of add() are staged on the host and reach the tree as ONE set per flush (next sample / remove /
+        # update, or MAX_PENDING adds): an env step then costs no kernel launch and no host<->device traffic here
+        self._pend_idx, self._pend_val = [], []
+
+    MAX_PENDING = 1024
+    MAX_PRIORITY = "max"  # add(key, MAX_PRIORITY): the tree's max_recorded_priority at the time the add reaches the tree
+
+    @property
+    def _sum_tree(self):
+        """The device tree with every staged add applied (what the reference's attribute of this name holds)."""
+        self.flush()
+        return self._tree
+
+    def flush(self) -> None:
+        if not self._pend_idx:
+            return
+        idx = np.asarray(self._pend_idx, dtype=np.int32)
+        val = np.asarray(self._pend_val, dtype=np.float64)
+        self._pend_idx, self._pend_val = [], []
+        d_idx, d_val = self._to_device(idx, torch.int32), self._to_device(val, torch.float64)
+        if np.isnan(val).any():  # MAX_PRIORITY entries: resolved on the device, no read-back
+            d_val = torch.where(torch.isnan(d_val), self._tree._max_dev, d_val)
+        self._tree.set_device(d_idx, d_val)
 
     def _transform(self, priority):
         return 0.0 if priority == 0.0 else priority**self._priority_exponent
 
     def add(self, key, priority) -> None:
         super().add(key)
-        if priority is None:
-            priority = 0.0
-        value = float(self._transform(priority))
-        assert value >= 0.0, "Values must be positive."
-        # one-leaf set on the device, no synchronisation (the value was validated on the host)
-        idx = torch.tensor([self._key_to_index[key]], dtype=torch.int32, device=self.device)
-        val = torch.tensor([value], dtype=torch.float64, device=self.device)
-        self._sum_tree.set_device(idx, val)
+        if isinstance(priority, str) and priority == self.MAX_PRIORITY:
+            value = float("nan")  # (the recorded maximum is already in the leaves' transformed domain)
+        else:
+            if priority is None:
+                priority = 0.0
+            value = float(self._transform(priority))
+            assert value >= 0.0, "Values must be positive."
+        # Staged: consecutive adds append at consecutive dense indices (distinct leaves), so one set over the staged
+        # block leaves every node with the bits of the one-leaf sets in the same order (sum_tree.py:20-47).
+        self._pend_idx.append(self._key_to_index[key])
+        self._pend_val.append(value)
+        if len(self._pend_idx) >= self.MAX_PENDING:
+            self.flush()
 
     def add_bulk(self, keys, priorities=None) -> None:
         start = len(self._index_to_key)
         super().add_bulk(keys)
         pr = np.zeros(len(keys)) if priorities is None else np.asarray(priorities, np.float64)
         pr = np.where(pr == 0.0, 0.0, pr**self._priority_exponent)
-        self._sum_tree.set(np.arange(start, start + len(keys), dtype=np.int32), pr)
+        self.flush()
+        self._tree.set(np.arange(start, start + len(keys), dtype=np.int32), pr)
 
     def update(self, keys, priorities) -> None:
         if not isinstance(keys, np.ndarray):
             keys = np.asarray([keys], dtype=np.int32)
         priorities = np.where(priorities == 0.0, 0.0, priorities**self._priority_exponent)
         k2i = self._key_to_index
-        self._sum_tree.set(np.fromiter((k2i[k] for k in keys.tolist()), dtype=np.int32), priorities)
+        self.flush()
+        self._tree.set(np.fromiter((k2i[k] for k in keys.tolist()), dtype=np.int32), priorities)
 
     def update_device(self, indices: torch.Tensor, priorities: torch.Tensor) -> None:
         """TD-error writeback without leaving the GPU: ``indices`` are the dense indices returned by
@@ -211,12 +241,14 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         torch's float64 pow (not part of the bit-exact contract, like the reference's own libm pow)."""
         if self._priority_exponent != 1.0:
             priorities = torch.where(priorities == 0.0, priorities, priorities**self._priority_exponent)
-        self._sum_tree.set_device(indices, priorities)
+        self.flush()
+        self._tree.set_device(indices, priorities)
 
     def remove(self, key) -> None:
         index = self._key_to_index[key]
         last_index = len(self._index_to_key) - 1
-        self._sum_tree.swap_remove_device(index, last_index)  # samplers.py:92-102 on the device
+        self.flush()
+        self._tree.swap_remove_device(index, last_index)  # samplers.py:92-102 on the device
         super().remove(key)
 
     def sample(self, size: int):
@@ -241,7 +273,8 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
             pu = self._pu = dict(dev=self._to_device(host, torch.float64), next=0, size=size, state=state)
         k = pu["next"]
         pu["next"] = k + 1
-        return self._sum_tree.query_device(pu["dev"][k], unit=True)
+        self.flush()
+        return self._tree.query_device(pu["dev"][k], unit=True)
 
     def _next_units(self, size: int) -> torch.Tensor:
         pu = getattr(self, "_pu", None)

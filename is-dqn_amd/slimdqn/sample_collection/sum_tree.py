@@ -22,7 +22,7 @@ from slimdqn import _hip
 
 
 class SumTree:
-    def __init__(self, capacity: int, device: str = "cuda:0") -> None:
+    def __init__(self, capacity: int, device: str | None = None) -> None:
         assert capacity > 0, "Capacity to sum tree must be positive."
         _hip.require_gpu()
         self._lib = _hip.lib()
@@ -31,7 +31,8 @@ class SumTree:
         self._capacity = capacity
         self._depth = int(depth.value)
         self._first_leaf_offset = int(first.value)
-        self.device = torch.device(device)
+        self.device = _hip.resolve_device(device)
+        _hip.bind_device(self.device)
         self._nodes_dev = torch.zeros(int(n_nodes.value), dtype=torch.float64, device=self.device)
         self._max_dev = torch.ones(1, dtype=torch.float64, device=self.device)
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -45,7 +46,7 @@ class SumTree:
         _hip.check(
             self._lib.isdqn_tree_set(
                 _hip.ptr(self._nodes_dev), self._depth, _hip.ptr(indices), _hip.ptr(values), n,
-                _hip.ptr(self._max_dev), _hip.ptr(self._status), _hip.stream_ptr(),
+                _hip.ptr(self._max_dev), _hip.ptr(self._status), _hip.stream_ptr(self.device),
             ),
             "isdqn_tree_set",
         )
@@ -59,7 +60,7 @@ class SumTree:
         _hip.check(
             self._lib.isdqn_tree_query(
                 _hip.ptr(self._nodes_dev), self._depth, _hip.ptr(targets), n, 1 if unit else 0, _hip.ptr(out),
-                _hip.ptr(self._status), _hip.stream_ptr(),
+                _hip.ptr(self._status), _hip.stream_ptr(self.device),
             ),
             "isdqn_tree_query",
         )
@@ -69,7 +70,7 @@ class SumTree:
         """samplers.py:89-103 on the device: leaf[index] <- leaf[last_index]; leaf[last_index] <- 0."""
         _hip.check(
             self._lib.isdqn_tree_swap_remove(
-                _hip.ptr(self._nodes_dev), self._depth, int(index), int(last_index), _hip.ptr(self._status), _hip.stream_ptr()
+                _hip.ptr(self._nodes_dev), self._depth, int(index), int(last_index), _hip.ptr(self._status), _hip.stream_ptr(self.device)
             ),
             "isdqn_tree_swap_remove",
         )

@@ -121,7 +121,7 @@ def test_entry_point_end_to_end_on_synthetic_env(tmp_path, prioritized):
             "-horizon", "50", "-at", "cnn", "-ne", "2", "-ntspe", "60", "-utd", "4", "-nis", "20", "-ed", "100", "-nbi", "2", "-ln",
             "-tuf", "16", "-env", "synthetic"] + (["-per"] if prioritized else [])
     gathered = run(argv, root=str(tmp_path))
-    assert len(gathered) == 2 and gathered[0].shape == (1, 3)
+    assert len(gathered) == 2 and gathered[0].shape == (1, 4)  # (avg_return, avg_length, n_training_steps, env steps/s) of one replica
     out = tmp_path / "atari" / "exp_output" / "smoke_Synthetic"
     params = json.load(open(out / "parameters.json"))
     assert params["shared_parameters"]["features"] == [8, 8, 8, 16] and params["isdqn"]["n_bellman_iterations"] == 2

@@ -36,3 +36,53 @@ def test_graph_replay_equals_eager_steps(workload):
     # and the step really trained
     fresh = _replica(workload)
     assert not torch.equal(fresh.eng.params, graphed.eng.params)
+
+
+@pytest.mark.parametrize("prioritized", [False, True])
+def test_agent_update_online_params_graphed_equals_eager(prioritized):
+    """The drop-in trainer gets the captured step: `iSDQN.update_online_params` on a device replay replays a one-step
+    hipGraph (isdqn.py:55-62).  Two agents, one with use_graph=False, are fed the same environment stream through a
+    buffer that grows, fills up and evicts (capacity 48 < 90 adds); with the prioritized sampler new elements enter at
+    the recorded maximum (staged leaf writes, resolved on the device) and TD errors are written back.  Parameters, Adam
+    state, accumulated losses and the sum tree must be bit-identical after every update."""
+    from slimdqn.networks.isdqn import iSDQN
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import PrioritizedSamplingDistribution, UniformSamplingDistribution
+
+    K, A, B, C = 3, 5, 8, 48
+
+    def make(use_graph):
+        agent = iSDQN(0, (84, 84, 4), A, K, [8, 12, 16, 24], True, False, "cnn", 2e-4, 0.99, 3, 2, 6, adam_eps=1.5e-4,
+                      batch_size=B, use_graph=use_graph)
+        sampler = PrioritizedSamplingDistribution(5, C) if prioritized else UniformSamplingDistribution(5)
+        rb = ReplayBuffer(sampler, B, C, update_horizon=3, gamma=0.99)
+        if prioritized:
+            agent.priority_writeback = True
+        return agent, rb
+
+    (eager, rb_e), (graphed, rb_g) = make(False), make(True)
+    assert torch.equal(eager._engine.params, graphed._engine.params)
+    rng = np.random.default_rng(0)
+    n_updates = 0
+    for step in range(1, 91):
+        obs = rng.integers(0, 256, (84, 84), dtype=np.uint8)
+        a, r, term = int(rng.integers(0, A)), float(rng.choice([-1.0, 0.0, 1.0])), bool(rng.random() < 0.08)
+        for rb in (rb_e, rb_g):
+            kw = dict(priority=rb._sampling_distribution.MAX_PRIORITY) if prioritized else {}
+            rb.add(TransitionElement(obs, a, r, term, term), **kw)
+        if step > 14:
+            for agent, rb in ((eager, rb_e), (graphed, rb_g)):
+                agent.update_online_params(step, rb)
+                agent.update_target_params(step)
+            if step % 2 == 0:
+                n_updates += 1
+                for name in ("params", "adam_m", "adam_v", "adam_count", "losses_accum"):
+                    x, y = getattr(eager._engine, name), getattr(graphed._engine, name)
+                    assert torch.equal(x, y), f"step {step}: {name} differs between the eager and the captured step"
+                if prioritized:
+                    ta, tb = rb_e._sampling_distribution._sum_tree, rb_g._sampling_distribution._sum_tree
+                    assert torch.equal(ta._nodes_dev, tb._nodes_dev) and torch.equal(ta._max_dev, tb._max_dev)
+    assert n_updates >= 30 and graphed._graphed is not None and eager._graphed is None
+    if prioritized:
+        rb_g._sampling_distribution._sum_tree.check_status()
+        assert rb_g._sampling_distribution._sum_tree.max_recorded_priority >= 1.0
