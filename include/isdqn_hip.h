@@ -122,7 +122,7 @@ typedef struct isdqn_net_config {
     int32_t n_features;                   /* len(features) (isdqn.py:19)                               */
     int32_t features[ISDQN_MAX_FEATURES]; /* cnn: 3 conv widths then dense widths; fc: dense widths     */
     int32_t n_actions;                    /* A                                                         */
-    int32_t n_heads;                      /* 1 + n_bellman_iterations  (isdqn.py:34-41)                */
+    int32_t n_heads;                      /* 1 + n_bellman_iterations (isdqn.py:34-41); 1 = DQN / TF-DQN */
     int32_t layer_norm;                   /* 0/1 (dqn.py:56, 63, 70, 97)                               */
     int32_t batch_size;                   /* B: learn_on_batch runs the network on 2B rows (isdqn.py:95) */
     int32_t precision;                    /* ISDQN_PRECISION_*                                         */
@@ -195,6 +195,21 @@ int isdqn_net_learn_on_batch(const isdqn_net_config* cfg, float* params, float* 
 /* Loss only, no update: iSDQN.loss_on_batch (isdqn.py:92-103). */
 int isdqn_net_loss_on_batch(const isdqn_net_config* cfg, const float* params, const isdqn_batch* batch, float* losses,
                             float* q_values, float* targets, void* workspace, void* stream);
+
+/* DQN.learn_on_batch / DQN.loss_on_batch (slimdqn/networks/dqn.py:59-83): the baselines on the same kernels.
+ * cfg->n_heads == 1 (one head of n_actions outputs; K = 1): head 0 of the states is regressed on
+ * r + (1 - terminal) * gamma^n * max_a head 0 of the next states.
+ *   - isdqn_net_learn_on_batch / isdqn_net_loss_on_batch with n_heads == 1 is TF-DQN (tfdqn.py:55-80: the next
+ *     states go through the SAME parameters, stop-gradient target);
+ *   - the *_target forms take the next states through `target_params` (DQN: a copy refreshed every
+ *     target_update_frequency steps by the caller, dqn.py:49-50).  losses[1] is the batch mean (dqn.py:69-70). */
+int isdqn_net_learn_on_batch_target(const isdqn_net_config* cfg, float* params, const float* target_params, float* adam_m,
+                                    float* adam_v, int32_t* adam_count, const isdqn_batch* batch, float* losses,
+                                    float* losses_accum, float* q_values, float* targets, double* priorities,
+                                    void* workspace, void* stream);
+int isdqn_net_loss_on_batch_target(const isdqn_net_config* cfg, const float* params, const float* target_params,
+                                   const isdqn_batch* batch, float* losses, float* q_values, float* targets,
+                                   void* workspace, void* stream);
 
 /* iSDQN.shift_params (isdqn.py:111-125): head k <- head k+1 on the last Dense; moments untouched. */
 int isdqn_net_shift_params(const isdqn_net_config* cfg, float* params, void* stream);

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
 // q_values/targets/priorities and per-workgroup partials of the per-head loss sums and of the head
 // bias gradient (column sums of dout); loss_finalize_kernel reduces them in a fixed order.
 constexpr int TD_ROWS = 64;
-__global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, int B, int K, int A, int nha_p,
+__global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, int B, int K, int oh, int A, int nha_p,
                                                  const int* __restrict__ action, const float* __restrict__ reward,
                                                  const uint8_t* __restrict__ terminal, float gamma_n,
                                                  float* __restrict__ dout, float* __restrict__ q_values,
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, in
     for (int k = wave; k < K; k += 4) {
         float d = 0.f, td = 0.f;
         if (on) {
-            float qv = q[(int64_t)b * nha_p + (1 + k) * A + a];
+            float qv = q[(int64_t)b * nha_p + (oh + k) * A + a];
             const float* nq = q + (int64_t)(B + b) * nha_p + k * A;
             float mx = nq[0];
             for (int j = 1; j < A; ++j) mx = fmaxf(mx, nq[j]);
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, in
     if (dout != nullptr) {
         for (int i = tid; i < TD_ROWS * K; i += 256) {
             int bl = i / K, k = i - bl * K;
-            if (b0 + bl < B) dout[(int64_t)(b0 + bl) * nha_p + (1 + k) * A + s_action[bl]] = s_d[i];
+            if (b0 + bl < B) dout[(int64_t)(b0 + bl) * nha_p + (oh + k) * A + s_action[bl]] = s_d[i];
         }
         // column sums over this workgroup's rows: column (1+k)*A + a' collects rows whose action is a'
         for (int c = tid; c < nha_p; c += 256) {
@@ -416,7 +416,7 @@ struct HeadChainParams {
     const float* bias;  // [O]
     const float* gamma; // hidden LayerNorm scale / bias, or null
     const float* beta;
-    int B, S, F, Fp, O, Op, K, A;
+    int B, S, F, Fp, O, Op, K, A, oh;  // oh: online head k + oh is regressed on head k (1: iS-DQN, 0: single head)
     const int* action;
     const float* reward;
     const uint8_t* terminal;
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool on = s < S && k0 + u < K;
-                const float* wr = p.W + (int64_t)(on ? (1 + k0 + u) * A + act[s] : 0) * Fp;
+                const float* wr = p.W + (int64_t)(on ? (p.oh + k0 + u) * A + act[s] : 0) * Fp;
 #pragma unroll
                 for (int j = 0; j < COLS; ++j) {
                     const int c = tid + j * HC_THREADS;
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
             a = act[0];
 #pragma unroll
             for (int i = 1; i < SMAX; ++i) a = s == i ? act[i] : a;
-            const float qv = s_q[s * Op + (1 + k) * A + a];
+            const float qv = s_q[s * Op + (p.oh + k) * A + a];
             const float* nq = s_q + (S + s) * Op + k * A;
             float mx = nq[0];
             for (int j = 1; j < A; ++j) mx = fmaxf(mx, nq[j]);
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
         const float dd = 2.f * d * inv_b;
         s_d[tid] = dd;
         s_td[tid] = td;
-        s_dq[s * Op + (1 + k) * A + a] = dd;
+        s_dq[s * Op + (p.oh + k) * A + a] = dd;
     }
     __syncthreads();
     for (int i = tid; i < S * Op; i += HC_THREADS) {
@@ -1069,6 +1069,7 @@ static ConvGeom conv_geom(const Layer& l) {
 struct NetInput {
     const uint8_t* frames; int64_t frame_stride; const int* frame_ids; int paired_B;  // cnn
     const float* obs; const float* obs2; int obs_split;                             // fc
+    int id_pitch = 0, id_off = 0;                                                   // cnn, unpaired: see FrameSrc
 };
 
 template <int BM, int PASSES, bool U8>
@@ -1078,7 +1079,7 @@ static int launch_conv_fwd(const Layer& l, const float* params, const NetInput& 
     p.g = conv_geom(l);
     p.W = MatSrc{params + l.w_off, l.K, l.cout_p, l.K, 1};
     p.in = act_in;
-    p.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win};
+    p.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win, in.id_pitch, in.id_off};
     p.bias = params + l.b_off;
     p.gamma = l.has_ln ? params + l.g_off : nullptr;
     p.beta = l.has_ln ? params + l.be_off : nullptr;
@@ -1106,7 +1107,7 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     if (lds > 150 * 1024 || (l.is_u8 && (l.win < 8 || l.cin > 4))) return ISDQN_OK;  // (frame ids of a stack live in 4 registers)
     ip.W = MatSrc{params + l.w_off, l.K, l.cout_p, l.K, 1};
     ip.in = act_in;
-    ip.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win};
+    ip.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win, in.id_pitch, in.id_off};
     ip.bias = params + l.b_off;
     ip.gamma = l.has_ln ? params + l.g_off : nullptr;
     ip.beta = l.has_ln ? params + l.be_off : nullptr;
@@ -1320,7 +1321,7 @@ static int launch_conv_wgrad(const Layer& l, const NetInput& in, const float* ac
     p.n_pix = n_img * l.npix;
     p.DZ = MatSrc{dz, l.cout_p, p.n_pix, l.cout_p, 1};
     p.in = act_in;
-    p.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win};
+    p.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win, in.id_pitch, in.id_off};
     p.slabs = slabs;
     p.scale = U8 ? (1.0f / 255.0f) : 1.0f;
     p.tiles_n = ceil_div(l.K, 64);
@@ -1353,7 +1354,7 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
     wp.d_R = FastDiv((uint32_t)wp.R);
     wp.d_dzchunk = FastDiv((uint32_t)(l.cout_p / 8));
     wp.dz = dz; wp.in = act_in;
-    wp.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win};
+    wp.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win, in.id_pitch, in.id_off};
     wp.slabs = slabs;
     wp.scale = l.is_u8 ? (1.0f / 255.0f) : 1.0f;
     wp.n_img = n_img; wp.G = l.wgi_G;
@@ -1599,7 +1600,8 @@ static int chain(SideStream* ss, hipStream_t signaller, hipStream_t waiter) {
 
 static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v, int32_t* adam_count,
                          const isdqn_batch* batch, float* losses, float* loss_accum, float* q_values, float* targets,
-                         double* priorities, void* workspace, void* stream, bool learn, float* grad_out) {
+                         double* priorities, void* workspace, void* stream, bool learn, float* grad_out,
+                         const float* target_params = nullptr) {
     int rc;
     const Plan* Pp = cached_plan(cfg, &rc);
     if (!Pp) return rc;
@@ -1612,7 +1614,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     if (cfg->arch == ISDQN_ARCH_FC) ISDQN_REQUIRE(batch->next_state != nullptr, ISDQN_ERR_ARG, "fc needs next_state");
     if (learn) ISDQN_REQUIRE(adam_m && adam_v && adam_count, ISDQN_ERR_ARG, "null optimizer state");
     const bool x3 = cfg->precision == ISDQN_PRECISION_BF16X3;
-    const int B = P.B, K = P.n_heads - 1;
+    const int B = P.B, K = P.K;
     float* ws = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     NetInput in{batch->frames, batch->frame_stride, batch->frame_ids, B, batch->state, batch->next_state, B};
@@ -1622,7 +1624,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     const Layer& head = P.L[P.n_layers - 1];
     int hc_S = 0, hc_wg = 0;
     static const bool hc_disabled = ISDQN_DEV_ENV("ISDQN_NO_HEAD_CHAIN");
-    if (learn && !hc_disabled && P.n_layers >= 2 && hid.kind == 1 && !hid.is_head && hid.has_relu &&
+    if (learn && !hc_disabled && target_params == nullptr && P.n_layers >= 2 && hid.kind == 1 && !hid.is_head && hid.has_relu &&
         hid.out_p <= HC_THREADS * HC_MAX_COLS && hid.out_p % 8 == 0) {
         // transitions per workgroup: the per-transition phases scale with S (the kernel is instruction-issue bound) while
         // every workgroup streams the whole head matrix from L2, so S follows the batch: about 256 workgroups
@@ -1637,10 +1639,22 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     SideStream* ss = learn ? side_stream() : nullptr;
     hipStream_t wst = ss ? ss->stream : st;  // stream of the weight gradients
 
-    // ---- forward on concat(state, next_state) (isdqn.py:95) ----
-    rc = net_forward(P, x3, params, in, P.N2, B, ws, ws + P.q_off, st, hc_S ? P.n_layers - 1 : -1,
-                     hc_S ? P.n_layers - 2 : -1);
-    if (rc) return rc;
+    if (target_params != nullptr) {
+        // DQN (dqn.py:74-88): the next states go through the TARGET parameters, the states through the online ones: two
+        // forwards of B images each over the same workspace, q rows [B, 2B) first, then rows [0, B) (+ z of every layer)
+        const int stack = cfg->arch == ISDQN_ARCH_CNN ? cfg->obs_c : 0;
+        NetInput nx{batch->frames, batch->frame_stride, batch->frame_ids, 0, batch->next_state, nullptr, 0, 2 * stack, stack};
+        rc = net_forward(P, x3, target_params, nx, B, 0, ws, ws + P.q_off + (int64_t)B * P.nha_p, st);
+        if (rc) return rc;
+        NetInput on{batch->frames, batch->frame_stride, batch->frame_ids, 0, batch->state, nullptr, 0, 2 * stack, 0};
+        rc = net_forward(P, x3, params, on, B, B, ws, ws + P.q_off, st);
+        if (rc) return rc;
+    } else {
+        // ---- forward on concat(state, next_state) (isdqn.py:95) ----
+        rc = net_forward(P, x3, params, in, P.N2, B, ws, ws + P.q_off, st, hc_S ? P.n_layers - 1 : -1,
+                         hc_S ? P.n_layers - 2 : -1);
+        if (rc) return rc;
+    }
 
     // ---- targets, loss, dL/dq ----
     float* qv = q_values ? q_values : ws + P.qv_off;
@@ -1660,7 +1674,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         hp.W = params + head.w_off; hp.bias = params + head.b_off;
         hp.gamma = hid.has_ln ? params + hid.g_off : nullptr;
         hp.beta = hid.has_ln ? params + hid.be_off : nullptr;
-        hp.B = B; hp.S = hc_S; hp.F = hid.out_f; hp.Fp = hid.out_p; hp.O = P.nha; hp.Op = P.nha_p; hp.K = K;
+        hp.B = B; hp.S = hc_S; hp.F = hid.out_f; hp.Fp = hid.out_p; hp.O = P.nha; hp.Op = P.nha_p; hp.K = K; hp.oh = P.oh;
         hp.A = P.n_actions;
         hp.action = batch->action; hp.reward = batch->reward; hp.terminal = batch->terminal;
         hp.gamma_n = cfg->gamma_n;
@@ -1700,7 +1714,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         }
     } else {
         hipLaunchKernelGGL(td_kernel, dim3(n_blk), dim3(256), 2 * TD_ROWS * K * sizeof(float), st, ws + P.q_off, B, K,
-                           P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n,
+                           P.oh, P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n,
                            learn ? ws + P.dout_off : nullptr, qv, tg, priorities, loss_part, dbh_part);
         ISDQN_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(ceil_div(K, 16) + ceil_div(P.nha_p, 16)), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p,
@@ -1943,6 +1957,24 @@ extern "C" int isdqn_net_loss_on_batch(const isdqn_net_config* cfg, const float*
                          targets, nullptr, workspace, stream, false, nullptr);
 }
 
+// DQN.learn_on_batch / loss_on_batch (dqn.py:59-83): separate target parameters for the next states.
+extern "C" int isdqn_net_learn_on_batch_target(const isdqn_net_config* cfg, float* params, const float* target_params,
+                                               float* adam_m, float* adam_v, int32_t* adam_count, const isdqn_batch* batch,
+                                               float* losses, float* losses_accum, float* q_values, float* targets,
+                                               double* priorities, void* workspace, void* stream) {
+    ISDQN_REQUIRE(target_params != nullptr, ISDQN_ERR_ARG, "null target_params");
+    return learn_or_loss(cfg, params, adam_m, adam_v, adam_count, batch, losses, losses_accum, q_values, targets,
+                         priorities, workspace, stream, true, nullptr, target_params);
+}
+
+extern "C" int isdqn_net_loss_on_batch_target(const isdqn_net_config* cfg, const float* params, const float* target_params,
+                                              const isdqn_batch* batch, float* losses, float* q_values, float* targets,
+                                              void* workspace, void* stream) {
+    ISDQN_REQUIRE(target_params != nullptr, ISDQN_ERR_ARG, "null target_params");
+    return learn_or_loss(cfg, const_cast<float*>(params), nullptr, nullptr, nullptr, batch, losses, nullptr, q_values,
+                         targets, nullptr, workspace, stream, false, nullptr, target_params);
+}
+
 extern "C" int isdqn_net_shift_params(const isdqn_net_config* cfg, float* params, void* stream) {
     Plan P;
     int rc = build_plan(cfg, P);
@@ -1963,7 +1995,7 @@ extern "C" int isdqn_net_best_action(const isdqn_net_config* cfg, const float* p
     if (!Pp) return rc;
     const Plan& P = *Pp;
     ISDQN_REQUIRE(params && out_action && workspace, ISDQN_ERR_ARG, "null pointer");
-    ISDQN_REQUIRE(idx_network >= 0 && idx_network < P.n_heads - 1, ISDQN_ERR_ARG, "idx_network out of range");
+    ISDQN_REQUIRE(idx_network >= 0 && idx_network < P.K, ISDQN_ERR_ARG, "idx_network out of range");
     rc = check_input(cfg, frames, frame_stride, frame_ids, obs);
     if (rc) return rc;
     NetInput in{frames, frame_stride, frame_ids, 0, obs, nullptr, 0};
@@ -1971,7 +2003,7 @@ extern "C" int isdqn_net_best_action(const isdqn_net_config* cfg, const float* p
     hipStream_t st = (hipStream_t)stream;
     rc = net_forward(P, cfg->precision == ISDQN_PRECISION_BF16X3, params, in, 1, 0, ws, ws + P.q_off, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(64), 0, st, ws + P.q_off, P.n_actions, 1 + idx_network, out_action);
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(64), 0, st, ws + P.q_off, P.n_actions, P.oh + idx_network, out_action);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
 }

@@ -49,6 +49,10 @@ struct Plan {
     Layer L[MAX_LAYERS];
     int B, N2;
     int n_heads, n_actions, nha, nha_p;
+    // K regressed heads; head k + oh (online rows) is regressed on head k (next-state rows).  iS-DQN: n_heads = 1 + K,
+    // oh = 1 (isdqn.py:96-98).  A single head (n_heads = 1) is TF-DQN: K = 1, oh = 0 -- the head is regressed on its own
+    // stop-gradient target (tfdqn.py:68-80).
+    int K, oh;
     int64_t n_params;
     // workspace (float offsets unless noted)
     int64_t q_off, dout_off, da_off, slab_off, qv_off, tg_off, dbh_off, adam_tab_off, lpart_off;
@@ -70,7 +74,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
                   "architecture_type must be cnn or fc (impala is outside the hot-path scope)");
     ISDQN_REQUIRE(cfg->n_features >= (cfg->arch == ISDQN_ARCH_CNN ? 3 : 0) && cfg->n_features <= ISDQN_MAX_FEATURES,
                   ISDQN_ERR_ARG, "bad n_features");
-    ISDQN_REQUIRE(cfg->n_actions >= 1 && cfg->n_heads >= 2, ISDQN_ERR_ARG, "need n_actions >= 1 and n_heads >= 2");
+    ISDQN_REQUIRE(cfg->n_actions >= 1 && cfg->n_heads >= 1, ISDQN_ERR_ARG, "need n_actions >= 1 and n_heads >= 1");
     ISDQN_REQUIRE(cfg->batch_size >= 1 && cfg->batch_size <= 4096, ISDQN_ERR_ARG, "batch_size must be in [1, 4096]");
     ISDQN_REQUIRE(cfg->precision == ISDQN_PRECISION_BF16X3 || cfg->precision == ISDQN_PRECISION_BF16, ISDQN_ERR_ARG,
                   "bad precision");
@@ -78,6 +82,8 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
     P.B = cfg->batch_size;
     P.N2 = 2 * P.B;
     P.n_heads = cfg->n_heads;
+    P.K = cfg->n_heads >= 2 ? cfg->n_heads - 1 : 1;
+    P.oh = cfg->n_heads >= 2 ? 1 : 0;
     P.n_actions = cfg->n_actions;
     P.nha = cfg->n_heads * cfg->n_actions;
     P.nha_p = round_up(P.nha, 8);
@@ -265,11 +271,11 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
     P.dout_off = region("dout", (int64_t)P.B * P.nha_p);
     P.da_off = region("da", P.da_floats);
     P.slab_off = region("slab", P.slab_floats);
-    P.qv_off = region("q_values", (int64_t)P.B * (P.n_heads - 1));
-    P.tg_off = region("targets", (int64_t)P.B * (P.n_heads - 1));
+    P.qv_off = region("q_values", (int64_t)P.B * P.K);
+    P.tg_off = region("targets", (int64_t)P.B * P.K);
     P.dbh_off = region("dbh", P.nha_p);
     P.adam_tab_off = region("adam_consts", 64);
-    P.lpart_off = region("loss_partials", (int64_t)P.B * (P.n_heads - 1 + P.nha_p));
+    P.lpart_off = region("loss_partials", (int64_t)P.B * (P.K + P.nha_p));
     P.ws_bytes = off * 4;
     return ISDQN_OK;
 }

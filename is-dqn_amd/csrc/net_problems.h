@@ -24,11 +24,12 @@ struct FrameSrc {
     int stack;
     int paired_B;  // > 0: learn layout ids[b][2*stack] and images [0,B) = states, [B,2B) = next states
     int H, W;
+    int id_pitch = 0, id_off = 0;  // unpaired: image j reads ids[j * id_pitch + id_off + c] (0: rows of `stack` ids) -- one half of a learn-layout table
     __device__ __forceinline__ int frame_id(int j, int c) const {
         if (paired_B > 0) {
             return j < paired_B ? ids[(int64_t)j * 2 * stack + c] : ids[(int64_t)(j - paired_B) * 2 * stack + stack + c];
         }
-        return ids[(int64_t)j * stack + c];
+        return ids[(int64_t)j * (id_pitch ? id_pitch : stack) + id_off + c];
     }
     // 8 horizontally adjacent pixels (ix0 .. ix0+7) of row iy of frame `id`, zero outside the frame; exact in
     // bf16.  Branch-free: one unaligned 8-byte load from a clamped position, then a 64-bit shift moves the

@@ -34,6 +34,8 @@ _ISDQN = [
     ("-bn", "--batch_norm", dict(action="store_true", default=False, help="Flag to add batch norm.")),
     ("-tuf", "--target_update_frequency", dict(type=int, default=200, help="Number of training steps before updating the target Q-network. (T)")),
 ]
+_DQN = [_ISDQN[1], _ISDQN[3]]             # add_dqn_arguments: layer_norm, target_update_frequency (parser_argument.py:229-232)
+_TFDQN = [_ISDQN[1], _ISDQN[2], _ISDQN[3]]  # add_tfdqn_arguments: layer_norm, batch_norm, target_update_frequency (:235-239)
 # extras of this build (not in the reference): kept out of parameters.json comparisons by living in their own group
 _ENGINE = [
     ("-prec", "--precision", dict(type=str, default="bf16x3", choices=["bf16x3", "bf16"], help="MFMA precision of the HIP engine.")),
@@ -54,6 +56,14 @@ def add_base_arguments(parser: argparse.ArgumentParser) -> List[str]:
 
 def add_isdqn_arguments(parser: argparse.ArgumentParser) -> List[str]:
     return _add(parser, _ISDQN)
+
+
+def add_dqn_arguments(parser: argparse.ArgumentParser) -> List[str]:
+    return _add(parser, _DQN)
+
+
+def add_tfdqn_arguments(parser: argparse.ArgumentParser) -> List[str]:
+    return _add(parser, _TFDQN)
 
 
 def add_engine_arguments(parser: argparse.ArgumentParser) -> List[str]:

@@ -90,7 +90,7 @@ class QNetEngine:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
             self.adam_count = torch.zeros(1, dtype=torch.int32, device=self.device)
-            K = self.n_heads - 1
+            K = self.n_regressed = self.n_heads - 1 if self.n_heads >= 2 else 1  # a single head (DQN / TF-DQN) regresses itself
             self.losses = torch.zeros(K, dtype=torch.float32, device=self.device)
             self.losses_accum = torch.zeros(K, dtype=torch.float32, device=self.device)
             self.q_values = torch.zeros(batch_size, K, dtype=torch.float32, device=self.device)
@@ -252,6 +252,30 @@ class QNetEngine:
         else:
             rc = self.lib.isdqn_net_learn_on_batch_debug(*args, _hip.ptr(grad_out))
         _hip.check(rc, "isdqn_net_learn_on_batch")
+        return self.losses
+
+    def learn_on_batch_target(self, batch: _hip.Batch, target_params: torch.Tensor) -> torch.Tensor:
+        """DQN step (dqn.py:59-72): next states through `target_params`, in-place update of the online parameters."""
+        _hip.check(
+            self.lib.isdqn_net_learn_on_batch_target(
+                ctypes.byref(self.cfg), _hip.ptr(self.params), _hip.ptr(target_params), _hip.ptr(self.adam_m), _hip.ptr(self.adam_v),
+                _hip.ptr(self.adam_count), ctypes.byref(batch), _hip.ptr(self.losses), _hip.ptr(self.losses_accum),
+                _hip.ptr(self.q_values), _hip.ptr(self.targets), _hip.ptr(self.priorities), _hip.ptr(self.workspace),
+                _hip.stream_ptr(self.device),
+            ),
+            "isdqn_net_learn_on_batch_target",
+        )
+        return self.losses
+
+    def loss_on_batch_target(self, batch: _hip.Batch, target_params: torch.Tensor, params=None) -> torch.Tensor:
+        p = self.params if params is None else params
+        _hip.check(
+            self.lib.isdqn_net_loss_on_batch_target(
+                ctypes.byref(self.cfg), _hip.ptr(p), _hip.ptr(target_params), ctypes.byref(batch), _hip.ptr(self.losses),
+                _hip.ptr(self.q_values), _hip.ptr(self.targets), _hip.ptr(self.workspace), _hip.stream_ptr(self.device),
+            ),
+            "isdqn_net_loss_on_batch_target",
+        )
         return self.losses
 
     def loss_on_batch(self, batch: _hip.Batch, params=None) -> torch.Tensor:

@@ -112,6 +112,14 @@ _SIGNATURES = {
         c_int32,
         [POINTER(NetConfig), c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "isdqn_net_learn_on_batch_target": (
+        c_int32,
+        [POINTER(NetConfig), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "isdqn_net_loss_on_batch_target": (
+        c_int32,
+        [POINTER(NetConfig), c_void_p, c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "isdqn_net_shift_params": (c_int32, [POINTER(NetConfig), c_void_p, c_void_p]),
     "isdqn_net_best_action": (
         c_int32,

@@ -1,0 +1,155 @@
+"""GPU parity of the DQN / TF-DQN baselines (slimdqn/networks/dqn.py:59-93, tfdqn.py:56-93) on the
+iS-DQN kernels with one head, against the CPU oracle (oracle/dqn.py), through the C ABI
+(isdqn_net_learn_on_batch[_target] with n_heads = 1).  Tolerances as in tests/test_gpu_network.py: targets / losses 1e-3."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_helpers import make_frame_batch, perturbed_params
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    pytest.param(((7, 9, 11, 13), 5, 6), id="tiny-B6"),
+    pytest.param(((32, 64, 64, 512), 9, 32), id="headline-arch-A9-B32"),
+    pytest.param(((8, 8, 8, 16), 4, 515), id="tiny-B515"),
+]
+
+
+def _agents(kind, feats, A, B, lr=1e-3):
+    from oracle.dqn import DQN as ODQN, TFDQN as OTF
+    from slimdqn.networks.dqn import DQN
+    from slimdqn.networks.tfdqn import TFDQN
+
+    params = perturbed_params(4, (84, 84, 4), feats, "cnn", A, True)
+    if kind == "dqn":
+        hip = DQN(0, (84, 84, 4), A, list(feats), True, "cnn", lr, 0.99, 3, 1, 4, adam_eps=1.5e-4, batch_size=B)
+        ora = ODQN(0, (84, 84, 4), A, list(feats), True, "cnn", lr, 0.99, 3, 1, 4, adam_eps=1.5e-4, params=params)
+    else:
+        hip = TFDQN(0, (84, 84, 4), A, list(feats), True, False, "cnn", lr, 0.99, 3, 1, 4, adam_eps=1.5e-4, batch_size=B)
+        ora = OTF(0, (84, 84, 4), A, list(feats), True, False, "cnn", lr, 0.99, 3, 1, 4, adam_eps=1.5e-4, params=params)
+    hip._engine.import_flax(params)
+    if kind == "dqn":
+        hip.target_params = hip.params.copy()
+    return hip, ora, params
+
+
+def _hip_batch(hip, frames, ids, action, reward, terminal):
+    from tests.gpu_helpers import device_batch
+
+    return device_batch(hip._engine, frames, ids, action, reward, terminal)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("kind", ["tfdqn", "dqn"])
+def test_loss_targets_and_adam_steps_match_the_oracle(kind, shape):
+    feats, A, B = shape
+    hip, ora, params = _agents(kind, feats, A, B)
+    frames, ids, action, reward, terminal, ref = make_frame_batch(B, A, seed=31, n_frames=B + 40)
+    eng = hip._engine
+    batch = _hip_batch(hip, frames, ids, action, reward, terminal)
+    if kind == "dqn":
+        # a target network that differs from the online one: perturb the online parameters after the copy (dqn.py:34)
+        bumped = {m: {n: (v + 0.01 * np.random.default_rng(1).normal(size=v.shape)).astype(np.float32) for n, v in l.items()}
+                  for m, l in params.items()}
+        eng.import_flax(bumped)
+        from oracle import network as onet
+
+        ora.params = onet.to_torch(bumped)
+        o_q, o_t, o_td = ora.loss_terms(ora.params, ora.target_params, ref)
+        loss = eng.loss_on_batch_target(batch, hip.target_params.tensor).cpu().numpy()
+    else:
+        o_q, o_t, o_td = ora.loss_terms(ora.params, ref)
+        loss = eng.loss_on_batch(batch).cpu().numpy()
+    assert loss.shape == (1,)
+    assert np.abs(eng.q_values.cpu().numpy()[:, 0] - o_q.detach().numpy()).max() < 1e-3
+    assert np.abs(eng.targets.cpu().numpy()[:, 0] - o_t.detach().numpy()).max() < 1e-3
+    assert abs(loss[0] - float(o_td.mean())) < 1e-3 * max(1.0, float(o_td.mean()))
+    # three gradient steps through the agent surface
+    p, st = ora.params, ora.optimizer_state
+    for step in range(3):
+        if kind == "dqn":
+            p, st, o_loss = ora.learn_on_batch(p, ora.target_params, st, ref)
+            _, _, h_loss = hip.learn_on_batch(hip.params, hip.target_params, hip.optimizer_state, _as_device_batch(hip, batch))
+        else:
+            p, st, o_loss = ora.learn_on_batch(p, st, ref)
+            _, _, h_loss = hip.learn_on_batch(hip.params, hip.optimizer_state, _as_device_batch(hip, batch))
+        # (after an update two fp32-class trajectories drift: Adam moves rounding-level gradients by a full +-lr)
+        assert abs(float(h_loss) - o_loss) < (1e-3 if step == 0 else 5e-3) * max(1.0, abs(o_loss)), f"step {step}"
+    got = hip.get_model()["params"]
+    for mod in p:
+        for leaf in p[mod]:
+            # three Adam steps of size lr: entries with rounding-level gradients may move the other way (see test_gpu_network.py)
+            assert np.abs(got[mod][leaf] - p[mod][leaf].numpy()).max() < 3 * 2.001e-3, (mod, leaf)
+    assert int(eng.adam_count.item()) == 3
+    for b in range(min(B, 4)):
+        assert hip.best_action(hip.params, ref.state[b]) == ora.best_action(p, ref.state[b])
+
+
+class _DB:
+    """DeviceBatch-shaped view of a C batch (what ReplayBuffer.sample returns)."""
+
+    def __init__(self, cb, B):
+        self.frames, self.frame_ids, self.action, self.reward, self.is_terminal = cb._keep[0], cb._keep[1], cb._keep[4], cb._keep[5], cb._keep[6]
+        self.frame_stride = cb.frame_stride
+
+
+def _as_device_batch(hip, cb):
+    return _DB(cb, hip._engine.batch_size)
+
+
+def test_dqn_target_refresh_cadence_and_tfdqn_logs():
+    """update_target_params: DQN copies the online parameters every T steps and reports the accumulated loss
+    (dqn.py:49-57); TF-DQN only reports (tfdqn.py:47-54)."""
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+
+    for kind in ("dqn", "tfdqn"):
+        hip, ora, _ = _agents(kind, (7, 9, 11, 13), 5, 8, lr=2e-4)
+        rb = ReplayBuffer(UniformSamplingDistribution(3), 8, 64, update_horizon=3, gamma=0.99)
+        from oracle.replay_buffer import ReplayBuffer as ORB, TransitionElement as OT
+        from oracle.samplers import UniformSamplingDistribution as OU
+
+        orb = ORB(OU(3), 8, 64, update_horizon=3, gamma=0.99)
+        rng = np.random.default_rng(0)
+        n_logs = 0
+        for step in range(1, 41):
+            obs = rng.integers(0, 256, (84, 84), dtype=np.uint8)
+            a, r, term = int(rng.integers(0, 5)), float(rng.choice([-1.0, 0.0, 1.0])), bool(rng.random() < 0.05)
+            rb.add(TransitionElement(obs, a, r, term, term))
+            orb.add(OT(obs, a, r, term, term))
+            if step > 12:
+                hip.update_online_params(step, rb)
+                ora.update_online_params(step, orb)
+                uh, lh = hip.update_target_params(step)
+                uo, lo = ora.update_target_params(step)
+                assert uh == uo
+                if uh:
+                    n_logs += 1
+                    # (a dozen Adam steps on 8-sample batches: the trajectories of two fp32-class implementations drift;
+                    # the first log is held to the parity bar, see tests/test_gpu_agent.py)
+                    tol = 1e-3 if n_logs == 1 else 1e-2
+                    assert abs(lh["loss"] - lo["loss"]) < tol * max(1.0, abs(lo["loss"])), (kind, step, lh, lo)
+                    if kind == "dqn":
+                        assert torch.equal(hip.target_params.tensor, hip.params.tensor)
+                        assert hip.target_params.tensor.data_ptr() != hip.params.tensor.data_ptr()
+        assert n_logs >= 6
+
+
+@pytest.mark.parametrize("algo", ["dqn", "tfdqn"])
+def test_entry_points_end_to_end_on_synthetic_env(algo, tmp_path):
+    import importlib
+
+    run = importlib.import_module(f"experiments.atari.{algo}").run
+    argv = ["-en", "smoke_Synthetic", "-s", "1", "-dw", "-f", "8", "8", "8", "16", "-rbc", "200", "-bs", "8", "-n", "1", "-horizon", "50",
+            "-at", "cnn", "-ne", "2", "-ntspe", "60", "-utd", "4", "-nis", "20", "-ed", "100", "-ln", "-tuf", "16", "-env", "synthetic"]
+    gathered = run(argv, root=str(tmp_path))
+    assert len(gathered) == 2
+    base = os.path.join(str(tmp_path), "atari", "exp_output", "smoke_Synthetic")
+    stored = json.load(open(os.path.join(base, "parameters.json")))
+    assert algo in stored and "target_update_frequency" in stored[algo] and "n_bellman_iterations" not in stored[algo]
+    assert os.path.exists(os.path.join(base, algo, "episode_returns_and_lengths", "1.json"))
+    assert os.path.exists(os.path.join(base, algo, "models", "1"))
