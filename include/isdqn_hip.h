@@ -171,7 +171,15 @@ typedef struct isdqn_batch {
     const int32_t* action;    /* [B]                                                           */
     const float* reward;      /* [B]  n-step discounted reward                                 */
     const uint8_t* terminal;  /* [B]                                                           */
+    int32_t flags;            /* ISDQN_BATCH_* (0 when in doubt)                               */
 } isdqn_batch;
+
+/* The workspace keeps a pre-split (bf16 hi + lo) mirror of the weights that the MFMA stages copy from.  Every entry point
+ * rebuilds it from `params` first -- `params` is caller-owned memory -- unless the caller passes this flag, promising that
+ * the previous call on this workspace was isdqn_net_learn_on_batch with the same `params` and that nothing has written
+ * `params` since (learn_on_batch leaves the mirror current: Adam writes both forms).  The captured multi-step graphs of
+ * slimdqn/_graph.py use it for steps 2..S of a replay. */
+#define ISDQN_BATCH_MIRROR_CURRENT 1
 
 /* DQNNet.apply on `n_rows` observations (dqn.py:47-103) -> q [n_rows][n_heads*n_actions].
  * cnn: image j reads frame_ids[j*stack .. j*stack+stack-1]; fc: obs [n_rows][obs_c]. */

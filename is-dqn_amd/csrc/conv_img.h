@@ -17,8 +17,8 @@ namespace isdqn {
 
 struct ConvImgParams {
     ConvGeom g;
-    MatSrc W;                // [cout_p][K] fp32
-    const float* in;         // fp32 NHWC input (if !U8)
+    MatSrc W;                // [cout_p][K], S8 mirror of the fp32 weights
+    const float* in;         // NHWC input activations, S8 (if !U8)
     FrameSrc fs;             // uint8 frames (if U8)
     const float *bias, *gamma, *beta;
     float scale;
@@ -155,12 +155,12 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             if (GA::CHUNKS % NTHR != 0 && !a_on[i]) continue;  // (whole multiples: no guard, no branch in the K loop)
-            bf16x8 hi, lo;
+            bf16x8 hi, lo;  // the weights come from the S8 mirror: staged by copy
             if constexpr (PASSES >= 2) {
-                split8(sa[slot][i], hi, lo);
+                s8_unpack(sa[slot][i], hi, lo);
                 *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
             } else {
-                round8(sa[slot][i], hi);
+                s8_unpack_hi(sa[slot][i], hi);
             }
             *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
         }
@@ -237,12 +237,12 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
-                bf16x8 hi, lo;
+                bf16x8 hi, lo;  // the input activations are stored S8: staged by copy
                 if constexpr (PASSES >= 3) {
-                    split8(v[u], hi, lo);
+                    s8_unpack(v[u], hi, lo);
                     if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + p.plane_elems + dst[u]) = lo;
                 } else {
-                    round8(v[u], hi);
+                    s8_unpack_hi(v[u], hi);
                 }
                 if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
             }
@@ -388,14 +388,8 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
                         else if (j < 8) fn.a_lo[j - 4] = read_frag<false, GA::PITCH>(na_lo, (j - 4) * 16, lane);
                         else if (j < 10) fn.b_hi[j - 8] = *reinterpret_cast<const bf16x8*>(img + b_org[j - 8] + tap_off);
                         else if (j < 12) fn.b_lo[j - 10] = *reinterpret_cast<const bf16x8*>(img + b_org[j - 10] + tap_off + p.plane_elems);
-                        else if (j < 16) {  // two elements per slot (packed convert / packed subtract)
-#pragma unroll
-                            for (int e = 2 * (j - 12); e < 2 * (j - 12) + 2; ++e) {
-                                const float v = sa[slot][0][e];
-                                const __bf16 h = (__bf16)v;
-                                c_hi[e] = h;
-                                c_lo[e] = (__bf16)(v - (float)h);
-                            }
+                        else if (j == 12) s8_unpack(sa[slot][0], c_hi, c_lo);  // S8 mirror: no conversion
+                        else if (j < 16) {
                         } else if (j == 16) *reinterpret_cast<bf16x8*>(st_lo) = c_lo;
                         else if (j == 17) *reinterpret_cast<bf16x8*>(st_hi) = c_hi;
                         else if (j == 18) fetch(slot, slice(s + 2 + PF) * GEMM_BK);
@@ -509,7 +503,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
                     ap[r] = (ch0 + r < g.cout) ? fmaxf(y, 0.f) : 0.f;
                     zp[r] = zv[nt][mt][r];
                 }
-                *reinterpret_cast<float4*>(p.act + pix * g.cout_p + ch0) = a;
+                s8_store_quad_paired(p.act + pix * g.cout_p, ch0, a.x, a.y, a.z, a.w);  // activations: S8 (consumers stage by copy)
                 if (j < p.z_img) *reinterpret_cast<float4*>(p.z + pix * g.cout_p + ch0) = zq;
             }
         }
@@ -568,7 +562,7 @@ static inline int conv_img_geometry(const ConvGeom& g, bool u8, int stack, int b
 struct ConvWgradImgParams {
     ConvGeom g;
     const float* dz;     // [n_img][npix][cout_p]
-    const float* in;     // fp32 NHWC input (if !U8)
+    const float* in;     // NHWC input activations, S8 (if !U8)
     FrameSrc fs;         // uint8 frames (if U8)
     float* slabs;        // [n_img_groups][cout_p][K]
     float scale;
@@ -638,12 +632,12 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
-                bf16x8 hi, lo;
+                bf16x8 hi, lo;  // the input activations are stored S8: staged by copy
                 if constexpr (PASSES >= 3) {
-                    split8(v[u], hi, lo);
+                    s8_unpack(v[u], hi, lo);
                     if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + plane_elems + dst[u]) = lo;
                 } else {
-                    round8(v[u], hi);
+                    s8_unpack_hi(v[u], hi);
                 }
                 if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
             }
@@ -722,12 +716,12 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
                 }
 #pragma unroll
                 for (int u = 0; u < FILL_BATCH; ++u) {
-                    bf16x8 hi, lo;
+                    bf16x8 hi, lo;  // dz is stored S8: staged by copy
                     if constexpr (PASSES >= 2) {
-                        split8(v[u], hi, lo);
+                        s8_unpack(v[u], hi, lo);
                         if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(dzi + p.dz_plane + dst[u]) = lo;
                     } else {
-                        round8(v[u], hi);
+                        s8_unpack_hi(v[u], hi);
                     }
                     if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(dzi + dst[u]) = hi;
                 }
@@ -816,7 +810,7 @@ static int launch_conv_wgrad_img(const ConvWgradImgParams& p, int n_img_groups, 
 // `da` never goes to HBM.  Per-workgroup partial sums of (dgamma, dbeta, dbias) go to part[wg][3][cin_p].
 struct ConvDgradImgParams {
     ConvGeom g;          // geometry of THIS conv layer (dz is its output gradient, da its input gradient)
-    const float* W;      // [cout_p][taps][cin_p]
+    const float* W;      // [cout_p][taps][cin_p], S8 mirror
     const float* dz;     // [n_img][hout][wout][cout_p]
     const float* z_in;   // pre-LayerNorm output of the layer below  [n_img][hin][win][cin_p]
     const float *gamma, *beta;  // LayerNorm of the layer below (nullptr: no LayerNorm, ReLU only)
@@ -921,12 +915,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             if (GA::CHUNKS % GEMM_THREADS != 0 && !a_on[i]) continue;  // (whole multiples: no guard, no branch in the K loop)
-            bf16x8 hi, lo;
+            bf16x8 hi, lo;  // the weights come from the S8 mirror: staged by copy
             if constexpr (PASSES >= 2) {
-                split8(sa[slot][i], hi, lo);
+                s8_unpack(sa[slot][i], hi, lo);
                 *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
             } else {
-                round8(sa[slot][i], hi);
+                s8_unpack_hi(sa[slot][i], hi);
             }
             *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
         }
@@ -966,12 +960,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
             }
 #pragma unroll
             for (int u = 0; u < FILL_BATCH; ++u) {
-                bf16x8 hi, lo;
+                bf16x8 hi, lo;  // dz is stored S8: staged by copy
                 if constexpr (PASSES >= 3) {
-                    split8(v[u], hi, lo);
+                    s8_unpack(v[u], hi, lo);
                     if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + p.dz_plane + dst[u]) = lo;
                 } else {
-                    round8(v[u], hi);
+                    s8_unpack_hi(v[u], hi);
                 }
                 if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
             }
@@ -1100,14 +1094,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
                     else if (jm < 8) fn.a_lo[jm - 4] = read_frag<true, GA::PITCH>(na_lo, (jm - 4) * 16, lane);
                     else if (jm < 10) fn.b_hi[jm - 8] = *reinterpret_cast<const bf16x8*>(img + b_org[jm - 8] + tap_off);
                     else if (jm < 12) fn.b_lo[jm - 10] = *reinterpret_cast<const bf16x8*>(img + b_org[jm - 10] + tap_off + p.dz_plane);
+                    else if (jm == 12) s8_unpack(sa[slot][0], c_hi, c_lo);  // S8 mirror: no conversion
                     else if (jm < 16) {
-#pragma unroll
-                        for (int e = 2 * (jm - 12); e < 2 * (jm - 12) + 2; ++e) {
-                            const float v = sa[slot][0][e];
-                            const __bf16 h = (__bf16)v;
-                            c_hi[e] = h;
-                            c_lo[e] = (__bf16)(v - (float)h);
-                        }
                     } else if (jm == 16) *reinterpret_cast<bf16x8*>(st_lo) = c_lo;
                     else if (jm == 17) *reinterpret_cast<bf16x8*>(st_hi) = c_hi;
                     else if (jm == 18) fetch(slot, slice(s + 2 + PF) * GEMM_BK);
@@ -1213,9 +1201,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int ch0 = mt * 16 + grp * 4;
-                if (ch0 < g.cin_p)
-                    *reinterpret_cast<float4*>(p.dz_in + pixel * g.cin_p + ch0) =
-                        float4{out[mt][0], out[mt][1], out[mt][2], out[mt][3]};
+                if (ch0 < g.cin_p)  // dz of the layer below: S8 (lane rows 2q / 2q+1 hold the two halves of a group)
+                    s8_store_quad_paired(p.dz_in + pixel * g.cin_p, ch0, out[mt][0], out[mt][1], out[mt][2], out[mt][3]);
             }
         }
     }

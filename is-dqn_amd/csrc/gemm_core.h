@@ -58,6 +58,94 @@ __device__ __forceinline__ void round8(const float (&v)[8], bf16x8& hi) {
     for (int i = 0; i < 8; ++i) hi[i] = (__bf16)v[i];
 }
 
+// "S8" split storage (round 2): a tensor whose MFMA consumers need it as bf16 hi + lo is stored pre-split by its
+// producer.  Every aligned group of 8 consecutive elements keeps its 32 bytes, but they hold the 8 hi halves (16 B)
+// followed by the 8 lo halves (16 B) instead of 8 fp32 values: addresses, chunk loads (two dwordx4) and footprints are
+// those of the fp32 tensor, and a consumer's staging is a plain copy -- no conversion VALU in any K loop or image fill.
+// hi + lo is exactly what split8() of the fp32 value gives, so results are bit-identical to splitting at the consumer.
+// Used for the weight mirror (written by the optimizer), the activations and the pre-activation gradients.
+__device__ __forceinline__ void s8_unpack(const float (&raw)[8], bf16x8& hi, bf16x8& lo) {
+    const f32x4 h = {raw[0], raw[1], raw[2], raw[3]}, l = {raw[4], raw[5], raw[6], raw[7]};
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+__device__ __forceinline__ void s8_unpack_hi(const float (&raw)[8], bf16x8& hi) {
+    const f32x4 h = {raw[0], raw[1], raw[2], raw[3]};
+    hi = __builtin_bit_cast(bf16x8, h);
+}
+// staging of one 8-element chunk into the hi (+ lo) planes, from either storage
+template <bool S8>
+__device__ __forceinline__ void chunk_planes(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    if constexpr (S8) s8_unpack(v, hi, lo);
+    else split8(v, hi, lo);
+}
+template <bool S8>
+__device__ __forceinline__ void chunk_hi(const float (&v)[8], bf16x8& hi) {
+    if constexpr (S8) s8_unpack_hi(v, hi);
+    else round8(v, hi);
+}
+// one whole group from 8 fp32 values (group = float pointer to the 32-byte group)
+__device__ __forceinline__ void s8_store_group(float* group, const float (&v)[8]) {
+    bf16x8 hi, lo;
+    split8(v, hi, lo);
+    reinterpret_cast<bf16x8*>(group)[0] = hi;
+    reinterpret_cast<bf16x8*>(group)[1] = lo;
+}
+// four consecutive elements c0 .. c0+3 (c0 % 4 == 0) of the row starting at `row`: one half of a group, two 8-byte stores
+__device__ __forceinline__ void s8_store_quad(float* row, int c0, float v0, float v1, float v2, float v3) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const float v[4] = {v0, v1, v2, v3};
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(v[i] - (float)h);
+    }
+    char* g = reinterpret_cast<char*>(row + (c0 & ~7)) + (c0 & 4) * 2;
+    *reinterpret_cast<bf16x4*>(g) = hi;
+    *reinterpret_cast<bf16x4*>(g + 16) = lo;
+}
+
+// The MFMA accumulator layout gives lane rows 2q and 2q+1 (lanes 16 apart) the two halves c0 = 8g and 8g+4 of one group.
+// Two v_permlane16_swap exchange them so that the even row holds the group's 8 hi halves and the odd row its 8 lo halves:
+// every lane then stores 16 contiguous bytes and a wave store covers whole 32-byte groups, like the fp32 float4 store
+// did (two 8-byte stores per lane leave 16-byte holes in every store instruction: measured 2.5 % of the step).
+// Must be executed by both lanes of a pair (same pixel, channels c0 and c0 ^ 4).
+__device__ __forceinline__ void s8_store_quad_paired(float* row, int c0, float v0, float v1, float v2, float v3) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const float v[4] = {v0, v1, v2, v3};
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(v[i] - (float)h);
+    }
+    const u32x2 h = __builtin_bit_cast(u32x2, hi), l = __builtin_bit_cast(u32x2, lo);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(h[0], l[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(h[1], l[1], false, false);
+    char* g = reinterpret_cast<char*>(row + (c0 & ~7)) + (c0 & 4) * 4;  // even row: the hi half, odd row: the lo half
+    *reinterpret_cast<u32x4*>(g) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+}
+
+// two adjacent elements c0, c0+1 (c0 even) / one element of the row starting at `row`
+__device__ __forceinline__ void s8_store_pair(float* row, int c0, float v0, float v1) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+    char* g = reinterpret_cast<char*>(row + (c0 & ~7)) + (c0 & 7) * 2;
+    *reinterpret_cast<bf16x2*>(g) = bf16x2{h0, h1};
+    *reinterpret_cast<bf16x2*>(g + 16) = bf16x2{(__bf16)(v0 - (float)h0), (__bf16)(v1 - (float)h1)};
+}
+__device__ __forceinline__ void s8_store_elem(float* row, int c, float v) {
+    const __bf16 h = (__bf16)v;
+    __bf16* g = reinterpret_cast<__bf16*>(row + (c & ~7)) + (c & 7);
+    g[0] = h;
+    g[8] = (__bf16)(v - (float)h);
+}
+
 // LDS image geometry (in bf16 elements)
 template <int ROWS, bool TR>
 struct TileGeom {
@@ -116,6 +204,15 @@ template <class P, class = void>
 struct KGroupsOf { static constexpr int value = 1; };
 template <class P>
 struct KGroupsOf<P, std::void_t<decltype(P::KG)>> { static constexpr int value = P::KG; };
+// operands stored S8 (problems that declare `static constexpr bool A_S8 / B_S8`): staged by copy
+template <class P, class = void>
+struct AS8Of { static constexpr bool value = false; };
+template <class P>
+struct AS8Of<P, std::void_t<decltype(P::A_S8)>> { static constexpr bool value = P::A_S8; };
+template <class P, class = void>
+struct BS8Of { static constexpr bool value = false; };
+template <class P>
+struct BS8Of<P, std::void_t<decltype(P::B_S8)>> { static constexpr bool value = P::B_S8; };
 
 template <class P>
 struct GemmTraits {
@@ -216,10 +313,10 @@ __global__ __launch_bounds__(GEMM_THREADS * KGroupsOf<P>::value) void gemm_kerne
             if (GA::CHUNKS % GEMM_THREADS != 0 && !a_on[i]) continue;
             bf16x8 hi, lo;
             if constexpr (PASSES >= 2) {
-                split8(sa[i], hi, lo);
+                chunk_planes<AS8Of<P>::value>(sa[i], hi, lo);
                 *reinterpret_cast<bf16x8*>(a_lo + a_lds[i]) = lo;
             } else {
-                round8(sa[i], hi);
+                chunk_hi<AS8Of<P>::value>(sa[i], hi);
             }
             *reinterpret_cast<bf16x8*>(a_hi + a_lds[i]) = hi;
         }
@@ -228,10 +325,10 @@ __global__ __launch_bounds__(GEMM_THREADS * KGroupsOf<P>::value) void gemm_kerne
             if (GB::CHUNKS % GEMM_THREADS != 0 && !b_on[i]) continue;
             bf16x8 hi, lo;
             if constexpr (PASSES >= 3) {
-                split8(sb[i], hi, lo);
+                chunk_planes<BS8Of<P>::value>(sb[i], hi, lo);
                 *reinterpret_cast<bf16x8*>(b_lo + b_lds[i]) = lo;
             } else {
-                round8(sb[i], hi);
+                chunk_hi<BS8Of<P>::value>(sb[i], hi);
             }
             *reinterpret_cast<bf16x8*>(b_hi + b_lds[i]) = hi;
         }

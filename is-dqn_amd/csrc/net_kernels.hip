@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int has_relu,
-                                                         float* __restrict__ act, float* __restrict__ z, int z_rows) {
+                                                         float* __restrict__ act, float* __restrict__ z, int z_rows, int act_s8) {
     extern __shared__ float s_row[];  // [3][Fp]: the summed row, gamma, beta
     __shared__ float s_red[2][4];
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict
             if (c >= F) y = 0.f;
             y2[e] = y; v2[e] = v;
         }
-        *reinterpret_cast<float2*>(act + (int64_t)row * Fp + c0) = make_float2(y2[0], y2[1]);
+        if (act_s8) s8_store_pair(act + (int64_t)row * Fp, c0, y2[0], y2[1]);  // hidden activations: S8; the head's q stays fp32
+        else *reinterpret_cast<float2*>(act + (int64_t)row * Fp + c0) = make_float2(y2[0], y2[1]);
         if (row < z_rows) *reinterpret_cast<float2*>(z + (int64_t)row * Fp + c0) = make_float2(v2[0], v2[1]);
     }
 }
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void ln_bwd_small_kernel(const float* __restri
                 dbias[r] += out[r];
             }
         }
-        if (on) *reinterpret_cast<float4*>(dz + (int64_t)row * Cp + ch0) = float4{out[0], out[1], out[2], out[3]};
+        if (on) s8_store_quad(dz + (int64_t)row * Cp, ch0, out[0], out[1], out[2], out[3]);  // dz: S8
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
                         o = rstd * (dy * gamma[c] - m1 - xh * m2);
                     }
                     dbias[i] += o;
-                    outr[c] = o;
+                    s8_store_elem(outr, c, o);
                 }
             }
         } else {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
                 if (c < Cp) {
                     float o = (c < C && zr[c] > 0.f) ? dr[c] : 0.f;
                     dbias[i] += o;
-                    outr[c] = o;
+                    s8_store_elem(outr, c, o);
                 }
             }
         }
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
                 y = fmaxf(y, 0.f);  // (the head chain requires a ReLU hidden layer)
                 if (c >= p.F) y = 0.f;
                 if (row_ok && c < Fp) {
-                    p.act[grow * Fp + c] = y;
+                    s8_store_elem(p.act + grow * Fp, c, y);  // hidden activations: S8 (read back by the head weight gradient)
                     if (r < S) p.z[grow * Fp + c] = v;
                 }
                 if (r < 2 * S && c < PA - 8) {
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
                     if (c < Fp) {
                         const float o = c < p.F ? rstd[s] * (da[s][j] - m1 - zv[s][j] * m2) : 0.f;
                         dbias[j] += o;
-                        p.dz[(int64_t)(b0 + s) * Fp + c] = o;
+                        s8_store_elem(p.dz + (int64_t)(b0 + s) * Fp, c, o);  // dz: S8
                     }
                 }
             }
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
                     if (c < Fp) {
                         const float o = (c < p.F && zv[s][j] > 0.f) ? da[s][j] : 0.f;
                         dbias[j] += o;
-                        p.dz[(int64_t)(b0 + s) * Fp + c] = o;
+                        s8_store_elem(p.dz + (int64_t)(b0 + s) * Fp, c, o);  // dz: S8
                     }
                 }
             }
@@ -955,7 +956,8 @@ struct AdamTable {
 };
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* __restrict__ p, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ consts, float lr,
-                                                   float b1, float b2, float eps, float* __restrict__ grad_out) {
+                                                   float b1, float b2, float eps, float* __restrict__ grad_out,
+                                                   float* __restrict__ mirror) {
     // A workgroup covers 16 float4 positions; 16 "slab lanes" per position split the slab reduction (up to a
     // few hundred split-K / per-image-group slabs for the conv kernels) and combine through LDS in a fixed
     // order, so the reduction is deterministic and never a long serial chain of dependent loads.
@@ -1012,6 +1014,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* _
     *reinterpret_cast<float4*>(m + o) = pm;
     *reinterpret_cast<float4*>(v + o) = pv;
     *reinterpret_cast<float4*>(p + o) = pp;
+    s8_store_quad(mirror, (int)o, pp.x, pp.y, pp.z, pp.w);  // S8 mirror of the updated parameters (read by the next step's MFMA stages)
 }
 
 // shift_params (isdqn.py:111-125): rows [0, nha-A) <- rows [A, nha) of the last Dense ([out][in] layout).
@@ -1056,6 +1059,23 @@ static long long* stamps_for(const char* kernel_tag) {
 static long long* stamps_for(const char*) { return nullptr; }
 #endif
 
+// fp32 master parameters -> S8 mirror (gemm_core.h): every 32-byte group of 8 values becomes 8 hi + 8 lo bf16.  The
+// MFMA consumers of the weights stage the mirror by copy.  Run at the head of every entry point that takes `params`:
+// the master is caller-owned memory (imports, head shifts, target copies happen outside this library).
+__global__ __launch_bounds__(256) void split_params_kernel(const float* __restrict__ p, float* __restrict__ mirror, int64_t n_groups) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups) return;
+    float v[8];
+    load8_aligned(p + g * 8, v);
+    s8_store_group(mirror + g * 8, v);
+}
+static int refresh_mirror(const Plan& P, const float* params, float* ws, hipStream_t st) {
+    const int64_t n_groups = P.n_params / 8;  // every tensor size is a multiple of 8 (padded widths)
+    hipLaunchKernelGGL(split_params_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st, params, ws + P.wsplit_off, n_groups);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
 static ConvGeom conv_geom(const Layer& l) {
     ConvGeom g;
     g.hin = l.hin; g.win = l.win; g.cin_p = l.cin_p; g.hout = l.hout; g.wout = l.wout;
@@ -1066,6 +1086,10 @@ static ConvGeom conv_geom(const Layer& l) {
     return g;
 }
 
+// Storage of the pre-activation gradients dz of hidden layers (bit 0 of the S8 operand masks below): S8, written so
+// by every producer (head chain, LayerNorm-backward epilogues and kernels); the head's dL/dq stays fp32
+constexpr int DZ_S8 = 1;
+
 struct NetInput {
     const uint8_t* frames; int64_t frame_stride; const int* frame_ids; int paired_B;  // cnn
     const float* obs; const float* obs2; int obs_split;                             // fc
@@ -1073,11 +1097,11 @@ struct NetInput {
 };
 
 template <int BM, int PASSES, bool U8>
-static int launch_conv_fwd(const Layer& l, const float* params, const NetInput& in, const float* act_in, int n_img,
+static int launch_conv_fwd(const Layer& l, const float* params, const float* wmir, const NetInput& in, const float* act_in, int n_img,
                            int z_img, float* act, float* z, hipStream_t st) {
     ConvFwd<BM, PASSES, U8> p;
     p.g = conv_geom(l);
-    p.W = MatSrc{params + l.w_off, l.K, l.cout_p, l.K, 1};
+    p.W = MatSrc{wmir + l.w_off, l.K, l.cout_p, l.K, 1};
     p.in = act_in;
     p.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win, in.id_pitch, in.id_off};
     p.bias = params + l.b_off;
@@ -1091,7 +1115,7 @@ static int launch_conv_fwd(const Layer& l, const float* params, const NetInput& 
 }
 
 // image-resident forward convolution (conv_img.h) when the input tile fits in LDS; generic engine otherwise
-static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int n_img,
+static int conv_fwd_img(const Layer& l, bool x3, const float* params, const float* wmir, const NetInput& in, const float* act_in, int n_img,
                         int z_img, float* act, float* z, hipStream_t st, bool* done) {
     *done = false;
     ConvImgParams ip;
@@ -1105,7 +1129,7 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
     const int lds = conv_img_geometry(ip.g, l.is_u8, l.cin, passes >= 3 ? 2 : 1, mt, passes >= 2 ? 2 : 1, ip.R, ip.Wp,
                                       ip.plane_elems, ip.PP);
     if (lds > 150 * 1024 || (l.is_u8 && (l.win < 8 || l.cin > 4))) return ISDQN_OK;  // (frame ids of a stack live in 4 registers)
-    ip.W = MatSrc{params + l.w_off, l.K, l.cout_p, l.K, 1};
+    ip.W = MatSrc{wmir + l.w_off, l.K, l.cout_p, l.K, 1};
     ip.in = act_in;
     ip.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win, in.id_pitch, in.id_off};
     ip.bias = params + l.b_off;
@@ -1139,30 +1163,30 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const NetI
          : kg2 ? launch_conv_fwd_img<4, 1, false, 2>(ip, st) : launch_conv_fwd_img<4, 1, false>(ip, st);
 }
 
-static int conv_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int n_img,
+static int conv_fwd(const Layer& l, bool x3, const float* params, const float* wmir, const NetInput& in, const float* act_in, int n_img,
                     int z_img, float* act, float* z, hipStream_t st) {
     bool done = false;
-    int rc = conv_fwd_img(l, x3, params, in, act_in, n_img, z_img, act, z, st, &done);
+    int rc = conv_fwd_img(l, x3, params, wmir, in, act_in, n_img, z_img, act, z, st, &done);
     if (rc || done) return rc;
     const bool small = l.cout_p <= 32;
     if (l.is_u8) {
-        if (x3) return small ? launch_conv_fwd<32, 2, true>(l, params, in, act_in, n_img, z_img, act, z, st)
-                             : launch_conv_fwd<64, 2, true>(l, params, in, act_in, n_img, z_img, act, z, st);
-        return small ? launch_conv_fwd<32, 1, true>(l, params, in, act_in, n_img, z_img, act, z, st)
-                     : launch_conv_fwd<64, 1, true>(l, params, in, act_in, n_img, z_img, act, z, st);
+        if (x3) return small ? launch_conv_fwd<32, 2, true>(l, params, wmir, in, act_in, n_img, z_img, act, z, st)
+                             : launch_conv_fwd<64, 2, true>(l, params, wmir, in, act_in, n_img, z_img, act, z, st);
+        return small ? launch_conv_fwd<32, 1, true>(l, params, wmir, in, act_in, n_img, z_img, act, z, st)
+                     : launch_conv_fwd<64, 1, true>(l, params, wmir, in, act_in, n_img, z_img, act, z, st);
     }
-    if (x3) return small ? launch_conv_fwd<32, 3, false>(l, params, in, act_in, n_img, z_img, act, z, st)
-                         : launch_conv_fwd<64, 3, false>(l, params, in, act_in, n_img, z_img, act, z, st);
-    return small ? launch_conv_fwd<32, 1, false>(l, params, in, act_in, n_img, z_img, act, z, st)
-                 : launch_conv_fwd<64, 1, false>(l, params, in, act_in, n_img, z_img, act, z, st);
+    if (x3) return small ? launch_conv_fwd<32, 3, false>(l, params, wmir, in, act_in, n_img, z_img, act, z, st)
+                         : launch_conv_fwd<64, 3, false>(l, params, wmir, in, act_in, n_img, z_img, act, z, st);
+    return small ? launch_conv_fwd<32, 1, false>(l, params, wmir, in, act_in, n_img, z_img, act, z, st)
+                 : launch_conv_fwd<64, 1, false>(l, params, wmir, in, act_in, n_img, z_img, act, z, st);
 }
 
 // C[split][M][N] = A . B^T over row-major sources.  a_tr/b_tr: the operand is stored [K][rows].
-template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, int PASSES, bool AL, bool A2PART, bool ADAM = false>
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, int PASSES, bool AL, bool A2PART, bool ADAM = false, int S8M = 0>
 static int launch_plain(const MatSrc& A, const float* A2, int a_split, const MatSrc& B, float* C, int ldc, int M,
                         int N, int K, int splits, int64_t slab_stride, hipStream_t st,
                         const AdamFuse* adam = nullptr) {
-    PlainGemm<BM, BN, WM, WN, ATR, BTR, PASSES, AL, A2PART, ADAM> p;
+    PlainGemm<BM, BN, WM, WN, ATR, BTR, PASSES, AL, A2PART, ADAM, S8M> p;
     if (adam) p.adam = *adam;
     p.A = A; p.B = B; p.A2 = A2; p.a_split = a_split; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
     p.tiles_m = ceil_div(M, BM); p.tiles_n = ceil_div(N, BN);
@@ -1183,26 +1207,26 @@ static int effective_splits(int K, int splits) {
     return ceil_div(ksteps, sps);
 }
 
-template <bool ATR, bool BTR, bool AL = true, bool A2PART = false>
+template <bool ATR, bool BTR, bool AL = true, bool A2PART = false, int S8M = 0>
 static int plain_big(bool x3, const MatSrc& A, const float* A2, int a_split, const MatSrc& B, float* C, int ldc,
                      int M, int N, int K, int splits, int64_t slab_stride, hipStream_t st) {
     if (x3)
-        return launch_plain<128, 128, 2, 2, ATR, BTR, 3, AL, A2PART>(A, A2, a_split, B, C, ldc, M, N, K, splits,
-                                                                     slab_stride, st);
-    return launch_plain<128, 128, 2, 2, ATR, BTR, 1, AL, A2PART>(A, A2, a_split, B, C, ldc, M, N, K, splits, slab_stride,
-                                                                 st);
+        return launch_plain<128, 128, 2, 2, ATR, BTR, 3, AL, A2PART, false, S8M>(A, A2, a_split, B, C, ldc, M, N, K, splits,
+                                                                                 slab_stride, st);
+    return launch_plain<128, 128, 2, 2, ATR, BTR, 1, AL, A2PART, false, S8M>(A, A2, a_split, B, C, ldc, M, N, K, splits,
+                                                                             slab_stride, st);
 }
 
 // 128 x 64 tiles: twice the workgroups of plain_big for GEMMs whose 128 x 128 grid cannot fill 256 CUs
-template <bool ATR, bool BTR>
+template <bool ATR, bool BTR, int S8M = 0>
 static int plain_narrow(bool x3, const MatSrc& A, const MatSrc& B, float* C, int ldc, int M, int N, int K, int splits,
                         int64_t slab_stride, hipStream_t st) {
-    if (x3) return launch_plain<128, 64, 2, 2, ATR, BTR, 3, true, false>(A, nullptr, 0, B, C, ldc, M, N, K, splits, slab_stride, st);
-    return launch_plain<128, 64, 2, 2, ATR, BTR, 1, true, false>(A, nullptr, 0, B, C, ldc, M, N, K, splits, slab_stride, st);
+    if (x3) return launch_plain<128, 64, 2, 2, ATR, BTR, 3, true, false, false, S8M>(A, nullptr, 0, B, C, ldc, M, N, K, splits, slab_stride, st);
+    return launch_plain<128, 64, 2, 2, ATR, BTR, 1, true, false, false, S8M>(A, nullptr, 0, B, C, ldc, M, N, K, splits, slab_stride, st);
 }
 
 // `skip_post`: leave the split-K slabs as they are (the head chain kernel finishes the layer for its own rows)
-static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInput& in, const float* act_in, int rows,
+static int dense_fwd(const Layer& l, bool x3, const float* params, const float* wmir, const NetInput& in, const float* act_in, int rows,
                      int z_rows, float* slab, float* act, float* z, hipStream_t st, bool skip_post = false) {
     MatSrc A, B;
     const float* A2 = nullptr;
@@ -1213,7 +1237,7 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInpu
     } else {
         A = MatSrc{act_in, l.in_p, rows, l.in_p, 1};
     }
-    B = MatSrc{params + l.w_off, l.in_p, l.out_f, l.in_p, 1};
+    B = MatSrc{wmir + l.w_off, l.in_p, l.out_f, l.in_p, 1};  // weights: S8 mirror (rows padded to in_p with zeros)
     // split-K partial products, row-interleaved: slab s of row m at slab[(m * ns + s) * out_p].  The ns partial rows of
     // one output row are one contiguous block (64 KB at the headline size) for whoever sums them; in [slab][row]
     // order they sit 1 MB apart, 32 pages per reader.
@@ -1223,20 +1247,19 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInpu
     int rc;
     if (l.in_unpadded_ld) {
         // caller-provided observations: no alignment promise; MatSrc bounds use the true widths
-        MatSrc Bu = B;
-        Bu.inner = l.in_f;
-        rc = A2 ? plain_big<false, false, false, true>(x3, A, A2, a_split, Bu, slab, ldc, rows, l.out_f, l.in_f,
-                                                       l.fwd_splits, slab_stride, st)
-                : plain_big<false, false, false, false>(x3, A, nullptr, 0, Bu, slab, ldc, rows, l.out_f, l.in_f,
-                                                        l.fwd_splits, slab_stride, st);
+        // (the observation operand bounds its own chunks to in_f; the mirror rows are read in whole aligned groups)
+        rc = A2 ? plain_big<false, false, false, true, 2>(x3, A, A2, a_split, B, slab, ldc, rows, l.out_f, l.in_f,
+                                                          l.fwd_splits, slab_stride, st)
+                : plain_big<false, false, false, false, 2>(x3, A, nullptr, 0, B, slab, ldc, rows, l.out_f, l.in_f,
+                                                           l.fwd_splits, slab_stride, st);
     } else {
-        rc = plain_big<false, false>(x3, A, nullptr, 0, B, slab, ldc, rows, l.out_f, l.K, l.fwd_splits, slab_stride,
-                                     st);
+        rc = plain_big<false, false, true, false, 3>(x3, A, nullptr, 0, B, slab, ldc, rows, l.out_f, l.K, l.fwd_splits, slab_stride,
+                                                     st);  // activations and weights both S8
     }
     if (rc || skip_post) return rc;
     hipLaunchKernelGGL(dense_post_kernel, dim3(rows), dim3(256), 3 * l.out_p * sizeof(float), st, slab, ns, slab_stride,
                        (int64_t)ldc, rows, l.out_f, l.out_p, params + l.b_off, l.has_ln ? params + l.g_off : nullptr,
-                       l.has_ln ? params + l.be_off : nullptr, l.has_relu, act, z, z_rows);
+                       l.has_ln ? params + l.be_off : nullptr, l.has_relu, act, z, z_rows, l.is_head ? 0 : 1);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
 }
@@ -1245,6 +1268,7 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const NetInpu
 static int net_forward(const Plan& P, bool x3, const float* params, const NetInput& in, int n_img, int z_img,
                        float* ws, float* q_out, hipStream_t st, int n_run = -1, int skip_post_layer = -1) {
     const float* prev = nullptr;
+    const float* wmir = ws + P.wsplit_off;  // refreshed by the caller (refresh_mirror) from `params`
     if (n_run < 0) n_run = P.n_layers;
     for (int i = 0; i < n_run; ++i) {
         const Layer& l = P.L[i];
@@ -1252,9 +1276,9 @@ static int net_forward(const Plan& P, bool x3, const float* params, const NetInp
         float* z = l.is_head ? nullptr : ws + l.z_off;
         int rc;
         if (l.kind == 0)
-            rc = conv_fwd(l, x3, params, in, prev, n_img, z_img, act, z, st);
+            rc = conv_fwd(l, x3, params, wmir, in, prev, n_img, z_img, act, z, st);
         else
-            rc = dense_fwd(l, x3, params, in, prev, n_img, l.is_head ? 0 : z_img, ws + P.slab_off, act, z, st,
+            rc = dense_fwd(l, x3, params, wmir, in, prev, n_img, l.is_head ? 0 : z_img, ws + P.slab_off, act, z, st,
                            i == skip_post_layer);
         if (rc) return rc;
         prev = act;
@@ -1291,11 +1315,11 @@ static int ln_bwd(const Layer& l, const float* params, const float* da, const fl
 }
 
 template <int BM, int PASSES>
-static int launch_conv_dgrad(const Layer& l, const float* params, const float* dz, float* da, int n_img,
+static int launch_conv_dgrad(const Layer& l, const float* wmir, const float* dz, float* da, int n_img,
                              hipStream_t st) {
     ConvDgrad<BM, PASSES> p;
     p.g = conv_geom(l);
-    p.W = params + l.w_off;
+    p.W = wmir + l.w_off;
     p.dz = dz; p.da = da; p.n_img = n_img;
     p.T = l.ksz / l.stride;
     p.Kc = p.T * p.T * l.cout_p;
@@ -1397,13 +1421,13 @@ static void add_reduce_job(ReduceJobs& jobs, const float* part, int n_rows, int 
     jobs.block_start[i + 1] = jobs.block_start[i] + ceil_div(width, 8);
 }
 
-static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const float* params, const float* dz, float* ws,
+static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const float* params, const float* wmir, const float* dz, float* ws,
                           int n_img, hipStream_t st, bool* done, ReduceJobs* jobs) {
     *done = false;
     if (!l.dgi_tiles || below.part_rows < n_img * l.dgi_tiles) return ISDQN_OK;
     ConvDgradImgParams dp;
     dp.g = conv_geom(l);
-    dp.W = params + l.w_off;
+    dp.W = wmir + l.w_off;
     dp.dz = dz;
     dp.z_in = ws + below.z_off;
     dp.gamma = below.has_ln ? params + below.g_off : nullptr;
@@ -1553,6 +1577,8 @@ extern "C" int isdqn_net_forward(const isdqn_net_config* cfg, const float* param
     NetInput in{frames, frame_stride, frame_ids, 0, obs, nullptr, 0};
     float* ws = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
+    rc = refresh_mirror(P, params, ws, st);
+    if (rc) return rc;
     rc = net_forward(P, cfg->precision == ISDQN_PRECISION_BF16X3, params, in, n_rows, 0, ws, ws + P.q_off, st);
     if (rc) return rc;
     // q_out is the unpadded (n_rows, nha) view
@@ -1638,18 +1664,30 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     }
     SideStream* ss = learn ? side_stream() : nullptr;
     hipStream_t wst = ss ? ss->stream : st;  // stream of the weight gradients
+    const float* wmir = ws + P.wsplit_off;
 
     if (target_params != nullptr) {
         // DQN (dqn.py:74-88): the next states go through the TARGET parameters, the states through the online ones: two
         // forwards of B images each over the same workspace, q rows [B, 2B) first, then rows [0, B) (+ z of every layer)
         const int stack = cfg->arch == ISDQN_ARCH_CNN ? cfg->obs_c : 0;
         NetInput nx{batch->frames, batch->frame_stride, batch->frame_ids, 0, batch->next_state, nullptr, 0, 2 * stack, stack};
+        rc = refresh_mirror(P, target_params, ws, st);
+        if (rc) return rc;
         rc = net_forward(P, x3, target_params, nx, B, 0, ws, ws + P.q_off + (int64_t)B * P.nha_p, st);
+        if (rc) return rc;
+        rc = refresh_mirror(P, params, ws, st);
         if (rc) return rc;
         NetInput on{batch->frames, batch->frame_stride, batch->frame_ids, 0, batch->state, nullptr, 0, 2 * stack, 0};
         rc = net_forward(P, x3, params, on, B, B, ws, ws + P.q_off, st);
         if (rc) return rc;
     } else {
+        // The optimizer writes the updated parameters in both forms, so a learn step leaves the mirror current; a caller
+        // that chains learn steps on one workspace with nothing else writing `params` in between says so
+        // (ISDQN_BATCH_MIRROR_CURRENT: the captured multi-step graphs) and the refresh is skipped.
+        if (!(batch->flags & ISDQN_BATCH_MIRROR_CURRENT)) {
+            rc = refresh_mirror(P, params, ws, st);
+            if (rc) return rc;
+        }
         // ---- forward on concat(state, next_state) (isdqn.py:95) ----
         rc = net_forward(P, x3, params, in, P.N2, B, ws, ws + P.q_off, st, hc_S ? P.n_layers - 1 : -1,
                          hc_S ? P.n_layers - 2 : -1);
@@ -1749,8 +1787,8 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         ISDQN_HIP_CHECK(hipGetLastError());
         MatSrc A{ws + P.dout_off, P.nha_p, B, head.out_p, 1};
         MatSrc Bm{ws + hid.act_off, head.in_p, B, head.in_p, 1};
-        return plain_big<true, true>(x3, A, nullptr, 0, Bm, ws + head.gw_off, head.in_p, head.out_p, head.in_p, B,
-                                     head.gw_slabs, head.w_size, s2);
+        return plain_big<true, true, true, false, 2>(x3, A, nullptr, 0, Bm, ws + head.gw_off, head.in_p, head.out_p, head.in_p, B,
+                                                     head.gw_slabs, head.w_size, s2);  // dL/dq fp32, hidden activations S8
     };
     for (int i = P.n_layers - 1; i >= 0; --i) {
         const Layer& l = P.L[i];
@@ -1803,7 +1841,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         dz_fused = false;
         if (i > 0) {
             if (l.kind == 0) {
-                rc = conv_dgrad_img(l, P.L[i - 1], x3, params, dz_cur, ws, B, st, &dz_fused, &red_jobs);
+                rc = conv_dgrad_img(l, P.L[i - 1], x3, params, wmir, dz_cur, ws, B, st, &dz_fused, &red_jobs);
                 if (rc) return rc;
             }
             if (l.kind == 1 && P.L[i - 1].kind == 0 && P.L[i - 1].cout_p == 64 && !l.in_unpadded_ld &&
@@ -1812,7 +1850,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 const Layer& below = P.L[i - 1];
                 auto launch = [&](auto prob) {
                     prob.A = MatSrc{dz_cur, dz_ld, B, l.out_p, 1};
-                    prob.B = MatSrc{params + l.w_off, l.in_p, l.out_f, l.in_p, 1};
+                    prob.B = MatSrc{wmir + l.w_off, l.in_p, l.out_f, l.in_p, 1};
                     prob.z = ws + below.z_off;
                     prob.gamma = below.has_ln ? params + below.g_off : nullptr;
                     prob.beta = below.has_ln ? params + below.be_off : nullptr;
@@ -1845,18 +1883,21 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
             if (dz_fused || head_chained) {
             } else if (l.kind == 0) {
                 const bool small = l.cin_p <= 32;
-                if (x3) rc = small ? launch_conv_dgrad<32, 3>(l, params, dz_cur, ws + P.da_off, B, st)
-                                   : launch_conv_dgrad<64, 3>(l, params, dz_cur, ws + P.da_off, B, st);
-                else rc = small ? launch_conv_dgrad<32, 1>(l, params, dz_cur, ws + P.da_off, B, st)
-                                : launch_conv_dgrad<64, 1>(l, params, dz_cur, ws + P.da_off, B, st);
+                if (x3) rc = small ? launch_conv_dgrad<32, 3>(l, wmir, dz_cur, ws + P.da_off, B, st)
+                                   : launch_conv_dgrad<64, 3>(l, wmir, dz_cur, ws + P.da_off, B, st);
+                else rc = small ? launch_conv_dgrad<32, 1>(l, wmir, dz_cur, ws + P.da_off, B, st)
+                                : launch_conv_dgrad<64, 1>(l, wmir, dz_cur, ws + P.da_off, B, st);
             } else {
                 // da[b][in_p] = sum_o dz[b][o] * W[o][in_p]
                 MatSrc A{dz_cur, dz_ld, B, l.out_p, 1};
-                MatSrc Bm{params + l.w_off, l.in_p, l.out_f, l.in_p, 1};
-                if (ceil_div(B, 128) * ceil_div(l.in_p, 128) < 200)
-                    rc = plain_narrow<false, true>(x3, A, Bm, ws + P.da_off, l.in_p, B, l.in_p, l.out_p, 1, 0, st);
+                MatSrc Bm{wmir + l.w_off, l.in_p, l.out_f, l.in_p, 1};
+                const bool narrow = ceil_div(B, 128) * ceil_div(l.in_p, 128) < 200;
+                if (l.is_head)  // dL/dq: fp32
+                    rc = narrow ? plain_narrow<false, true, 2>(x3, A, Bm, ws + P.da_off, l.in_p, B, l.in_p, l.out_p, 1, 0, st)
+                                : plain_big<false, true, true, false, 2>(x3, A, nullptr, 0, Bm, ws + P.da_off, l.in_p, B, l.in_p, l.out_p, 1, 0, st);
                 else
-                    rc = plain_big<false, true>(x3, A, nullptr, 0, Bm, ws + P.da_off, l.in_p, B, l.in_p, l.out_p, 1, 0, st);
+                    rc = narrow ? plain_narrow<false, true, DZ_S8 | 2>(x3, A, Bm, ws + P.da_off, l.in_p, B, l.in_p, l.out_p, 1, 0, st)
+                                : plain_big<false, true, true, false, DZ_S8 | 2>(x3, A, nullptr, 0, Bm, ws + P.da_off, l.in_p, B, l.in_p, l.out_p, 1, 0, st);
             }
             if (rc) return rc;
         }
@@ -1897,19 +1938,29 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
 
                 AdamFuse af{params + l.w_off, adam_m + l.w_off, adam_v + l.w_off, ws + P.adam_tab_off,
                             cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps,
-                            grad_out ? grad_out + l.w_off : nullptr};
+                            grad_out ? grad_out + l.w_off : nullptr, ws + P.wsplit_off + l.w_off};
                 // 64x64 tiles: the contraction is only B deep, the kernel lives off streaming p/m/v through the Adam
                 // epilogue, and 128x128 tiles would leave 100 workgroups for 256 CUs
-                rc = x3 ? launch_plain<64, 64, 2, 2, true, true, 3, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                       l.out_p, l.in_p, B, 1, 0, lws, &af)
-                        : launch_plain<64, 64, 2, 2, true, true, 1, true, false, true>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                       l.out_p, l.in_p, B, 1, 0, lws, &af);
+                // (operands: dz of a hidden layer -- or the fp32 dL/dq of the head -- and the S8 activations below it)
+                if (l.is_head)
+                    rc = x3 ? launch_plain<64, 64, 2, 2, true, true, 3, true, false, true, 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                             l.out_p, l.in_p, B, 1, 0, lws, &af)
+                            : launch_plain<64, 64, 2, 2, true, true, 1, true, false, true, 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                             l.out_p, l.in_p, B, 1, 0, lws, &af);
+                else
+                    rc = x3 ? launch_plain<64, 64, 2, 2, true, true, 3, true, false, true, DZ_S8 | 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                                     l.out_p, l.in_p, B, 1, 0, lws, &af)
+                            : launch_plain<64, 64, 2, 2, true, true, 1, true, false, true, DZ_S8 | 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                                     l.out_p, l.in_p, B, 1, 0, lws, &af);
+            } else if (l.in_unpadded_ld) {  // fc first layer: caller's fp32 observations
+                rc = plain_big<true, true, false, false, DZ_S8>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
+                                                                l.gw_slabs, l.w_size, lws);
+            } else if (l.is_head) {         // dL/dq is fp32, the hidden activations are S8
+                rc = plain_big<true, true, true, false, 2>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
+                                                           l.gw_slabs, l.w_size, lws);
             } else {
-                rc = l.in_unpadded_ld
-                         ? plain_big<true, true, false>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
-                                                        l.gw_slabs, l.w_size, lws)
-                         : plain_big<true, true>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
-                                                 l.gw_slabs, l.w_size, lws);
+                rc = plain_big<true, true, true, false, DZ_S8 | 2>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
+                                                                   l.gw_slabs, l.w_size, lws);
             }
         }
         if (rc) return rc;
@@ -1929,7 +1980,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         ISDQN_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, tab, params, adam_m, adam_v, ws + P.adam_tab_off,
-                       cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps, grad_out);
+                       cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps, grad_out, ws + P.wsplit_off);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
 }
@@ -2001,6 +2052,8 @@ extern "C" int isdqn_net_best_action(const isdqn_net_config* cfg, const float* p
     NetInput in{frames, frame_stride, frame_ids, 0, obs, nullptr, 0};
     float* ws = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
+    rc = refresh_mirror(P, params, ws, st);
+    if (rc) return rc;
     rc = net_forward(P, cfg->precision == ISDQN_PRECISION_BF16X3, params, in, 1, 0, ws, ws + P.q_off, st);
     if (rc) return rc;
     hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(64), 0, st, ws + P.q_off, P.n_actions, P.oh + idx_network, out_action);

@@ -56,6 +56,7 @@ struct Plan {
     int64_t n_params;
     // workspace (float offsets unless noted)
     int64_t q_off, dout_off, da_off, slab_off, qv_off, tg_off, dbh_off, adam_tab_off, lpart_off;
+    int64_t wsplit_off;  // S8 mirror of the parameter buffer (same offsets as the fp32 master; weights only are read from it)
     int64_t slab_floats, da_floats;
     int64_t ws_bytes;
     std::vector<std::pair<std::string, std::pair<int64_t, int64_t>>> regions;  // name -> (byte offset, byte size)
@@ -276,6 +277,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
     P.dbh_off = region("dbh", P.nha_p);
     P.adam_tab_off = region("adam_consts", 64);
     P.lpart_off = region("loss_partials", (int64_t)P.B * (P.K + P.nha_p));
+    P.wsplit_off = region("wsplit", P.n_params);
     P.ws_bytes = off * 4;
     return ISDQN_OK;
 }

@@ -77,13 +77,16 @@ struct AdamFuse {
     const float* consts;     // {1 - b1^t, 1 - b2^t}
     float lr, b1, b2, eps;
     float* grad_out;         // optional: also store the raw gradient (tests)
+    float* mirror;           // S8 mirror of p (same layout): the updated parameters are written in both forms
 };
 
+// S8M: bit 0 / bit 1 = operand A / B is stored S8 (gemm_core.h): staged by copy; such an operand is always chunk-aligned.
 template <int BM_, int BN_, int WM_, int WN_, bool ATR, bool BTR, int PASSES_, bool AL = true, bool A2PART = false,
-          bool ADAM = false>
+          bool ADAM = false, int S8M = 0>
 struct PlainGemm {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, PASSES = PASSES_;
     static constexpr bool A_TR = ATR, B_TR = BTR;
+    static constexpr bool A_S8 = (S8M & 1) != 0, B_S8 = (S8M & 2) != 0;
     MatSrc A, B;       // ROW: outer = rows, inner = K ; TR: outer = K, inner = rows
     const float* A2;   // optional second part of A (ROW only): rows >= a_split come from A2
     int a_split;
@@ -101,6 +104,12 @@ struct PlainGemm {
         int tm = bid % tiles_m, rest = bid / tiles_m;
         int tn = rest % tiles_n;
         t.split = rest / tiles_n;
+#if defined(ISDQN_ADAM_ROWMAJOR)
+        if constexpr (ADAM) {  // experiment: n-tiles fastest, so that the workgroups of an XCD stream adjacent pieces of the same p/m/v rows
+            tn = bid % tiles_n;
+            tm = bid / tiles_n;
+        }
+#endif
         if (t.split >= splits) return false;
         t.m0 = tm * BM;
         t.n0 = tn * BN;
@@ -116,17 +125,17 @@ struct PlainGemm {
                 const bool second = c.fixed >= a_split;
                 MatSrc s = A;
                 s.base = second ? A2 : A.base;
-                s.load<AL>(second ? c.fixed - a_split : c.fixed, var, v);
+                s.load<AL || A_S8>(second ? c.fixed - a_split : c.fixed, var, v);
             } else {
-                A.load<AL>(c.fixed, var, v);
+                A.load<AL || A_S8>(c.fixed, var, v);
             }
         } else {
-            A.load<AL>(var, c.fixed, v);
+            A.load<AL || A_S8>(var, c.fixed, v);
         }
     }
     __device__ __forceinline__ void load_b(const Tile&, const BCtx& c, int var, float (&v)[8]) const {
-        if constexpr (!BTR) B.load<AL>(c.fixed, var, v);
-        else B.load<AL>(var, c.fixed, v);
+        if constexpr (!BTR) B.load<AL || B_S8>(c.fixed, var, v);
+        else B.load<AL || B_S8>(var, c.fixed, v);
     }
     template <int MT, int NT>
     __device__ __forceinline__ void epilogue(const Tile& t, f32x4 (&acc)[MT][NT], int m_wave, int n_wave, int lane, char* smem) const {
@@ -186,6 +195,7 @@ struct PlainGemm {
                     *reinterpret_cast<f32x4*>(adam.m + off[it]) = nm;
                     *reinterpret_cast<f32x4*>(adam.v + off[it]) = nv;
                     *reinterpret_cast<f32x4*>(adam.p + off[it]) = np;
+                    s8_store_quad(adam.mirror, (int)off[it], np[0], np[1], np[2], np[3]);  // (tensor sizes < 2^31)
                 }
             }
             return;
@@ -219,7 +229,11 @@ struct DenseDgradLN {
     static constexpr int BM = BM_, BN = 64, WM = 4, WN = 1, PASSES = PASSES_;
     static constexpr int KG = KG_;  // K groups (gemm_core.h): the epilogue then sees one row tile per wave, 8 waves
     static constexpr bool A_TR = false, B_TR = true;
-    static constexpr int EPI_LDS_BYTES = 4 * KG_ * 3 * 64 * 4;
+    static constexpr bool A_S8 = true;  // dz of the dense layer: S8
+    static constexpr bool B_S8 = true;  // the weights come from the S8 mirror
+    static constexpr int TR_PITCH = 68;  // floats per staged row: 64 channels + 4 (bank spread of the transposed reads)
+    static constexpr int SP_BYTES = 4 * KG_ * 3 * 64 * 4;                  // per-wave partial sums
+    static constexpr int EPI_LDS_BYTES = SP_BYTES + 4 * KG_ * 16 * TR_PITCH * 4;  // + one 16-row x 64-channel tile per wave
     MatSrc A, B;
     const float* z;            // [M][ldc] pre-LayerNorm conv output (flat [b][pix][64])
     const float *gamma, *beta; // nullptr: ReLU only
@@ -256,6 +270,9 @@ struct DenseDgradLN {
             dg[nt] = db[nt] = dbias[nt] = 0.f;
         }
         const float inv_c = 1.f / (float)c_in;
+        // dz of the conv layer is stored S8 (groups of 8 channels of one row), but a lane owns channels li, 16 + li, ...:
+        // each wave transposes its rows through its own 16-row LDS tile and stores whole 32-byte groups
+        float* tr = reinterpret_cast<float*>(smem + SP_BYTES) + wave * 16 * TR_PITCH;
         // all pre-activations of this lane first (MT*4*NT independent loads in flight), then the arithmetic: loaded
         // inside the row loop, each row would wait for its own round trip
         float zall[MT][4][NT];
@@ -322,13 +339,26 @@ struct DenseDgradLN {
                         dbias[nt] += out[nt];
                     }
                 }
-                if (row_ok) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) dz_out[base + nt * 16 + li] = out[nt];
+                for (int nt = 0; nt < NT; ++nt) tr[(grp * 4 + r) * TR_PITCH + nt * 16 + li] = out[nt];
+                if (r == 3) {
+                    // the 16 rows of this row tile are staged (all four lane groups of THIS wave wrote them: the LDS unit
+                    // serves a wave's operations in order, and the reads below are waited for before the next tile's writes)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int chunk = lane + u * 64, rl = chunk >> 3, c8 = (chunk & 7) * 8;
+                        const int orow = m_wave + mt * 16 + rl;
+                        float v[8];
+                        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(tr + rl * TR_PITCH + c8);
+                        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(tr + rl * TR_PITCH + c8 + 4);
+                        v[0] = lo4[0]; v[1] = lo4[1]; v[2] = lo4[2]; v[3] = lo4[3];
+                        v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
+                        if (orow < M) s8_store_group(dz_out + (int64_t)orow * ldc + t.n0 + c8, v);
+                    }
                 }
             }
         // partial sums: over the 4 row groups of the wave, then over the 4 waves (fixed order)
-        float* sp = reinterpret_cast<float*>(smem);  // [4 * KG waves][3][64]
+        float* sp = reinterpret_cast<float*>(smem);  // [4 * KG waves][3][64] (in front of the transposition tiles)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             dg[nt] += __shfl_xor(dg[nt], 16); dg[nt] += __shfl_xor(dg[nt], 32);
@@ -366,9 +396,11 @@ template <int BM_, int PASSES_, bool U8>
 struct ConvFwd {
     static constexpr int BM = BM_, BN = 128, WM = 1, WN = 4, PASSES = PASSES_;
     static constexpr bool A_TR = false, B_TR = false;
+    static constexpr bool A_S8 = true;  // weights: S8 mirror
+    static constexpr bool B_S8 = !U8;   // input activations: S8 (uint8 frames are converted)
     static constexpr int EPI_LDS_BYTES = 0;
     ConvGeom g;
-    MatSrc W;            // [cout_p][K]
+    MatSrc W;            // [cout_p][K] (S8 mirror)
     const float* in;     // fp32 NHWC input (if !U8)
     FrameSrc fs;         // uint8 frames (if U8)
     const float *bias, *gamma, *beta;  // gamma == nullptr: no LayerNorm
@@ -471,7 +503,7 @@ struct ConvFwd {
                         ap[r] = (ch0 + r < g.cout) ? fmaxf(y, 0.f) : 0.f;
                         zp[r] = zv[mt][r];
                     }
-                    *reinterpret_cast<float4*>(act + (int64_t)pix * g.cout_p + ch0) = a;
+                    s8_store_quad_paired(act + (int64_t)pix * g.cout_p, ch0, a.x, a.y, a.z, a.w);
                     if (pix < z_pix) *reinterpret_cast<float4*>(z + (int64_t)pix * g.cout_p + ch0) = zq;
                 }
             }
@@ -489,9 +521,11 @@ template <int BM_, int PASSES_>
 struct ConvDgrad {
     static constexpr int BM = BM_, BN = 128, WM = 1, WN = 4, PASSES = PASSES_;
     static constexpr bool A_TR = true, B_TR = false;
+    static constexpr bool A_S8 = true;  // weights: S8 mirror
+    static constexpr bool B_S8 = true;  // dz: S8
     static constexpr int EPI_LDS_BYTES = 0;
     ConvGeom g;
-    const float* W;   // [cout_p][taps][cin_p]
+    const float* W;   // [cout_p][taps][cin_p] (S8 mirror)
     const float* dz;  // [n_img][hout][wout][cout_p]
     float* da;        // [n_img][hin][win][cin_p]
     int n_img, T, Kc; // T = ksz/stride taps per dim per class, Kc = T*T*cout_p
@@ -574,6 +608,8 @@ template <int PASSES_, bool U8>
 struct ConvWgrad {
     static constexpr int BM = 64, BN = 64, WM = 2, WN = 2, PASSES = PASSES_;
     static constexpr bool A_TR = true, B_TR = true;
+    static constexpr bool A_S8 = true;  // dz: S8
+    static constexpr bool B_S8 = !U8;  // input activations: S8
     static constexpr int EPI_LDS_BYTES = 0;
     ConvGeom g;
     MatSrc DZ;        // [n_pix][cout_p]: outer = pixels (K), inner = cout_p

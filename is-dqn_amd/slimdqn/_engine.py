@@ -213,8 +213,12 @@ class QNetEngine:
         return self.workspace[off.value // 4 : (off.value + size.value) // 4]
 
     # ------------------------------------------------------------------ C-ABI calls
-    def make_batch(self, *, frames=None, frame_stride=0, frame_ids=None, state=None, next_state=None, action=None, reward=None, terminal=None) -> _hip.Batch:
+    def make_batch(self, *, frames=None, frame_stride=0, frame_ids=None, state=None, next_state=None, action=None, reward=None, terminal=None,
+                   mirror_current: bool = False) -> _hip.Batch:
+        """``mirror_current``: promise that the previous call on this engine was learn_on_batch and nothing wrote the
+        parameters since (include/isdqn_hip.h, ISDQN_BATCH_MIRROR_CURRENT) -- only the captured multi-step graphs do."""
         b = _hip.Batch()
+        b.flags = _hip.BATCH_MIRROR_CURRENT if mirror_current else 0
         b.B = self.batch_size
         b.frames = _hip.ptr(frames)
         b.frame_stride = int(frame_stride)

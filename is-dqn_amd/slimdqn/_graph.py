@@ -42,9 +42,16 @@ class GraphedUpdate:
 
     def _make_batches(self) -> None:
         rb, eng = self.rb, self.eng
+        # steps 2..S of a replay follow a learn step of the same graph directly: the weight mirror is current (the first
+        # step of a replay rebuilds it: anything may have written the parameters between two replays)
         self.batches = [
             eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids[i], action=self.action[i],
                            reward=self.reward[i], terminal=self.terminal[i])
+            for i in range(self.frame_ids.shape[0])
+        ]
+        self.chained = [
+            eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids[i], action=self.action[i],
+                           reward=self.reward[i], terminal=self.terminal[i], mirror_current=True)
             for i in range(self.frame_ids.shape[0])
         ]
 
@@ -68,13 +75,13 @@ class GraphedUpdate:
             for s in range(self.S):
                 tree.query_device(self.block[s], out=self.indices, unit=True)
                 self._gather(self.indices, self.B, 0)
-                eng.learn_on_batch(self.batches[0])
+                eng.learn_on_batch(self.batches[0] if s == 0 else self.chained[0])
                 if self.writeback:
                     rb._sampling_distribution.update_device(self.indices, eng.priorities)
         else:
             self._gather(self.block, self.S * self.B, 0)  # rows of all S steps: the [S][B] buffers are contiguous
             for s in range(self.S):
-                eng.learn_on_batch(self.batches[s])
+                eng.learn_on_batch(self.batches[s] if s == 0 else self.chained[s])
 
     def _capture(self) -> None:
         # warm-up on a side stream (lazy one-time setup inside the library must not happen during capture)

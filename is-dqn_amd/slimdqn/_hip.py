@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("ISDQN_HIP_LIB") or os.path.join(os.path.dirname(_HERE
 OK = 0
 ERR_CAPACITY, ERR_NEGATIVE, ERR_SHAPE, ERR_EMPTY, ERR_RANGE, ERR_UNSUPPORTED, ERR_HIP, ERR_ARG = range(-1, -9, -1)
 STATUS_NEGATIVE_VALUE, STATUS_TARGET_RANGE, STATUS_EMPTY_TREE = 1, 2, 4
+BATCH_MIRROR_CURRENT = 1  # include/isdqn_hip.h: ISDQN_BATCH_MIRROR_CURRENT
 TREE_MAX_BATCH = 4096
 ARCH_CNN, ARCH_FC = 0, 1
 PRECISION_BF16X3, PRECISION_BF16 = 0, 1
@@ -68,6 +69,7 @@ class Batch(ctypes.Structure):
         ("action", c_void_p),
         ("reward", c_void_p),
         ("terminal", c_void_p),
+        ("flags", c_int32),
     ]
 
 
