@@ -69,6 +69,61 @@ __device__ __forceinline__ void xcd_image_tile(int wg, int n_img, int T, int& j,
     }
 }
 
+// Copy a dense channel-last S8 image [H][W][C] (C % 8 == 0, `src` = its first element) into an LDS image whose local pixel
+// (lr, xl), lr < Rl, xl < Wl, is source pixel (y0 + lr, x0 + xl) -- zeros outside the source (SAME padding / gradient
+// borders) -- at img[(lr * Wl + xl) * PP + c] (+ plane_elems for the lo plane).  The 8-channel chunks are dealt round-robin
+// to the NTHR threads and a thread WALKS its chunks: coordinates advance by additions and one carry per level instead of
+// two divisions per chunk (the fills of these kernels are bound by instruction issue: ~250 instructions per chunk before,
+// a third of a forward workgroup's life).  BATCH chunks are requested before the first one is written.
+template <int NTHR, int PLANES, int BATCH>
+__device__ __forceinline__ void fill_image_s8(__bf16* img, int plane_elems, const float* src, int H, int W, int C, int y0, int x0,
+                                              int Rl, int Wl, int PP, int tid, const FastDiv& d_cpp, const FastDiv& d_Wl) {
+    const int cpp = C >> 3, n_chunks = Rl * Wl * cpp;
+    uint32_t pix_u, cc_u, lr_u, xl_u;
+    d_cpp.divmod((uint32_t)tid, pix_u, cc_u);
+    d_Wl.divmod(pix_u, lr_u, xl_u);
+    int cc = (int)cc_u, lr = (int)lr_u, xl = (int)xl_u, pix = (int)pix_u;
+    // per-round advance (wave-uniform): NTHR chunks = dpix pixels + dcc chunks; dpix pixels = dpy rows + dpx columns
+    uint32_t dpix_u, dcc_u, dpy_u, dpx_u;
+    d_cpp.divmod((uint32_t)NTHR, dpix_u, dcc_u);
+    d_Wl.divmod(dpix_u, dpy_u, dpx_u);
+    const int dpix = (int)dpix_u, dcc = (int)dcc_u, dpy = (int)dpy_u, dpx = (int)dpx_u;
+    for (int c0 = tid; c0 - tid < n_chunks; ) {  // (uniform trip count: every thread runs the same number of rounds)
+        float v[BATCH][8];
+        int dst[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const bool on = c0 < n_chunks;
+            const int iy = y0 + lr, ix = x0 + xl;
+            const bool ok = on && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            load8_aligned(ok ? src + ((iy * W + ix) * C + cc * 8) : zero_chunk(), v[u]);
+            dst[u] = on ? pix * PP + cc * 8 : -1;
+            // advance to this thread's next chunk
+            c0 += NTHR;
+            cc += dcc;
+            const int carry_c = cc >= cpp ? 1 : 0;
+            cc -= carry_c ? cpp : 0;
+            pix += dpix + carry_c;
+            xl += dpx + carry_c;
+            lr += dpy;
+            const int carry_x = xl >= Wl ? 1 : 0;
+            xl -= carry_x ? Wl : 0;
+            lr += carry_x;
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            bf16x8 hi, lo;  // S8 source: staged by copy
+            if constexpr (PLANES >= 2) {
+                s8_unpack(v[u], hi, lo);
+                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + plane_elems + dst[u]) = lo;
+            } else {
+                s8_unpack_hi(v[u], hi);
+            }
+            if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
+        }
+    }
+}
+
 // Four waves; each owns all MT channel tiles of 32 output pixels.  (An eight-wave variant -- two waves per SIMD sharing
 // the image, channel halves per wave -- was measured slower: barrier-locked waves do not overlap each other.)
 // The uint8 first layer (MT = 2: 2048 workgroups of 38 KB LDS at the headline size) is asked to fit four workgroups per
@@ -110,7 +165,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
     int j, tile;
     xcd_image_tile((int)blockIdx.x, p.n_img, p.tiles_per_img, j, tile);
     const int p0 = tile * 128;
-    const int oy_min = p0 / g.wout;
+    const int oy_min = (int)g.d_wout.div((uint32_t)p0);
     const int row_base = oy_min * g.stride - g.pad;  // global input row of local row 0
 
     // Epilogue parameters (bias, gamma, beta of up to 64 channels): one float per thread is requested now and parked
@@ -216,37 +271,9 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
             }
         }
     } else {
-        // channel-last: img[lr][xp][cin_p], chunk = 8 channels of one padded pixel
-        const int cpp = g.cin_p / 8;
-        const int n_chunks = p.R * p.Wp * cpp;
-        for (int cb = 0; cb < n_chunks; cb += NTHR_ALL * FILL_BATCH) {
-            float v[FILL_BATCH][8];
-            int dst[FILL_BATCH];
-#pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {
-                const int c0 = cb + u * NTHR_ALL + tid_all;
-                const bool on = c0 < n_chunks;
-                const int cq = on ? c0 : 0;
-                uint32_t cc, pix, xp, lr;
-                p.d_chunk.divmod((uint32_t)cq, pix, cc);
-                p.d_Wp.divmod(pix, lr, xp);
-                const int iy = row_base + (int)lr, ix = (int)xp - g.pad;
-                const bool ok = on && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-                load8_aligned(ok ? p.in + ((((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + (int)cc * 8) : zero_chunk(), v[u]);
-                dst[u] = on ? ((int)pix * p.PP + (int)cc * 8) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {
-                bf16x8 hi, lo;  // the input activations are stored S8: staged by copy
-                if constexpr (PASSES >= 3) {
-                    s8_unpack(v[u], hi, lo);
-                    if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + p.plane_elems + dst[u]) = lo;
-                } else {
-                    s8_unpack_hi(v[u], hi);
-                }
-                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
-            }
-        }
+        // channel-last: img[lr][xp][PP], chunk = 8 channels of one padded pixel
+        fill_image_s8<NTHR_ALL, T::B_PLANES, FILL_BATCH>(img, p.plane_elems, p.in + (int64_t)j * g.hin * g.win * g.cin_p, g.hin, g.win,
+                                                         g.cin_p, row_base, -g.pad, p.R, p.Wp, p.PP, tid_all, p.d_chunk, p.d_Wp);
     }
 
     ISDQN_STAMP(1);  // fill loads consumed, LDS image written (this wave)
@@ -256,7 +283,9 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
     for (int nt = 0; nt < NT; ++nt) {
         int pp = p0 + wave * 32 + nt * 16 + (lane & 15);
         pp = pp < g.npix ? pp : g.npix - 1;  // lanes past the image compute a duplicate pixel; never stored
-        const int oy = pp / g.wout, ox = pp - oy * g.wout;
+        uint32_t oy_u, ox_u;
+        g.d_wout.divmod((uint32_t)pp, oy_u, ox_u);
+        const int oy = (int)oy_u, ox = (int)ox_u;
         const int ly0 = oy * g.stride - g.pad - row_base;  // >= 0 by construction
         const int lx0 = ox * g.stride;                     // padded column of tap kx = 0
         b_org[nt] = U8 ? (ly0 * p.Wp + lx0) : (ly0 * p.Wp + lx0) * p.PP;
@@ -572,7 +601,8 @@ struct ConvWgradImgParams {
     int in_plane;        // elements of one precision plane of the input image
     int PA, npix_pad;    // dz image: row pitch (elements), rows padded to a multiple of 32
     int dz_plane;        // elements of one precision plane of the dz image
-    FastDiv d_chunk, d_Wp, d_R, d_dzchunk;  // fill index math (see ConvImgParams)
+    FastDiv d_ncg;         // by n_col_groups
+    FastDiv d_chunk, d_Wp, d_R, d_dzchunk, d_npixpad;  // fill index math (see ConvImgParams); d_npixpad: by npix_pad
 };
 
 template <bool U8, int PASSES, int NTHR = GEMM_THREADS>
@@ -612,36 +642,8 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
             }
         }
     } else {
-        const int cpp = g.cin_p / 8;
-        const int n_chunks = R * Wp * cpp;
-        for (int cb = 0; cb < n_chunks; cb += NTHR * FILL_BATCH) {
-            float v[FILL_BATCH][8];
-            int dst[FILL_BATCH];
-#pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {
-                const int c0 = cb + u * NTHR + tid;
-                const bool on = c0 < n_chunks;
-                const int cq = on ? c0 : 0;
-                uint32_t cc, pix, xp, lr;
-                d_chunk.divmod((uint32_t)cq, pix, cc);
-                d_Wp.divmod(pix, lr, xp);
-                const int iy = row_base + (int)lr, ix = (int)xp - g.pad;
-                const bool ok = on && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-                load8_aligned(ok ? in + ((((int64_t)j * g.hin + iy) * g.win + ix) * g.cin_p + (int)cc * 8) : zero_chunk(), v[u]);
-                dst[u] = on ? ((int)pix * g.cin_p + (int)cc * 8) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {
-                bf16x8 hi, lo;  // the input activations are stored S8: staged by copy
-                if constexpr (PASSES >= 3) {
-                    s8_unpack(v[u], hi, lo);
-                    if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + plane_elems + dst[u]) = lo;
-                } else {
-                    s8_unpack_hi(v[u], hi);
-                }
-                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
-            }
-        }
+        fill_image_s8<NTHR, (PASSES >= 3 ? 2 : 1), FILL_BATCH>(img, plane_elems, in + (int64_t)j * g.hin * g.win * g.cin_p, g.hin, g.win, g.cin_p,
+                                                               row_base, -g.pad, R, Wp, g.cin_p, tid, d_chunk, d_Wp);
     }
 }
 
@@ -666,7 +668,9 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
     __bf16* img = dzi + A_PLANES * p.dz_plane;             // B_PLANES planes of the input image
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cg = (int)blockIdx.x % p.n_col_groups, ig = (int)blockIdx.x / p.n_col_groups;
+    uint32_t ig_u, cg_u;
+    p.d_ncg.divmod(blockIdx.x, ig_u, cg_u);
+    const int cg = (int)cg_u, ig = (int)ig_u;
     const int j0 = ig * p.G, j1 = min(p.n_img, j0 + p.G);
     const int grp = lane >> 4, li = lane & 15, q = li >> 2, pq = li & 3;
 
@@ -695,38 +699,9 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
     const int nsteps = p.npix_pad / GEMM_BK;
     for (int j = j0; j < j1; ++j) {
         __syncthreads();  // previous image fully consumed
-        // ---- dz image: [npix_pad][PA], rows >= npix are zero ----
-        {
-            constexpr int FILL_BATCH = 8;
-            const int cpr = g.cout_p / 8;
-            const int n_chunks = p.npix_pad * cpr;
-            for (int cb = 0; cb < n_chunks; cb += NTHR * FILL_BATCH) {
-                float v[FILL_BATCH][8];
-                int dst[FILL_BATCH];
-#pragma unroll
-                for (int u = 0; u < FILL_BATCH; ++u) {
-                    const int c0 = cb + u * NTHR + tid;
-                    const bool on = c0 < n_chunks;
-                    const int cq = on ? c0 : 0;
-                    uint32_t cc, pix;
-                    p.d_dzchunk.divmod((uint32_t)cq, pix, cc);
-                    const bool ok = on && (int)pix < g.npix;
-                    load8_aligned(ok ? p.dz + (((int64_t)j * g.npix + (int)pix) * g.cout_p + (int)cc * 8) : zero_chunk(), v[u]);
-                    dst[u] = on ? ((int)pix * p.PA + (int)cc * 8) : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < FILL_BATCH; ++u) {
-                    bf16x8 hi, lo;  // dz is stored S8: staged by copy
-                    if constexpr (PASSES >= 2) {
-                        s8_unpack(v[u], hi, lo);
-                        if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(dzi + p.dz_plane + dst[u]) = lo;
-                    } else {
-                        s8_unpack_hi(v[u], hi);
-                    }
-                    if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(dzi + dst[u]) = hi;
-                }
-            }
-        }
+        // ---- dz image: [npix_pad][PA], rows >= npix are zero (one "row" of npix_pad pixels for the walker) ----
+        fill_image_s8<NTHR, A_PLANES, 8>(dzi, p.dz_plane, p.dz + (int64_t)j * g.npix * g.cout_p, 1, g.npix, g.cout_p, 0, 0, 1, p.npix_pad,
+                                         p.PA, tid, p.d_dzchunk, p.d_npixpad);
         fill_input_image<U8, PASSES, NTHR>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, tid, p.d_chunk, p.d_Wp, p.d_R);
         __syncthreads();
 
@@ -862,10 +837,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     int cls = 0;
     while (cls + 1 < p.n_classes && tl >= p.cls_tile_start[cls + 1]) ++cls;
     const int q0 = (tl - p.cls_tile_start[cls]) * 128;  // first class-local pixel of this tile
-    const int cy = cls / g.stride, cx = cls % g.stride;
-    const int Ha = (g.hin - cy + g.stride - 1) / g.stride, Wb = (g.win - cx + g.stride - 1) / g.stride;
+    const int smask = g.stride - 1;  // (stride is a power of two: shifts and masks instead of divisions)
+    const int cy = cls >> g.stride_sh, cx = cls & smask;
+    const int Ha = (g.hin - cy + g.stride - 1) >> g.stride_sh, Wb = (g.win - cx + g.stride - 1) >> g.stride_sh;
     const int n_cls_pix = Ha * Wb;
-    const int py = (cy + g.pad) % g.stride, px = (cx + g.pad) % g.stride;
+    const int py = (cy + g.pad) & smask, px = (cx + g.pad) & smask;
 
     // LayerNorm parameters of the layer below for the epilogue: requested now (one float per thread), parked in LDS
     // after the fill (see conv_fwd_img_kernel)
@@ -937,40 +913,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
 #pragma unroll
     for (int d = 0; d < PF; ++d) fetch(d, slice(d) * GEMM_BK);
 
-    // ---- dz image of this sample into LDS (zero border) ----
-    {
-        constexpr int FILL_BATCH = 8;
-        const int cpp = g.cout_p / 8;
-        const int n_chunks = p.Hd * p.Wd * cpp;
-        for (int cb = 0; cb < n_chunks; cb += GEMM_THREADS * FILL_BATCH) {
-            float v[FILL_BATCH][8];
-            int dst[FILL_BATCH];
-#pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {
-                const int c0 = cb + u * GEMM_THREADS + tid;
-                const bool on = c0 < n_chunks;
-                const int cq = on ? c0 : 0;
-                uint32_t cc, pix, xp, yp;
-                p.d_chunk.divmod((uint32_t)cq, pix, cc);
-                p.d_Wd.divmod(pix, yp, xp);
-                const int oy = (int)yp - p.bt, ox = (int)xp - p.bt;
-                const bool ok = on && oy >= 0 && oy < g.hout && ox >= 0 && ox < g.wout;
-                load8_aligned(ok ? p.dz + ((((int64_t)j * g.hout + oy) * g.wout + ox) * g.cout_p + (int)cc * 8) : zero_chunk(), v[u]);
-                dst[u] = on ? ((int)pix * p.PPd + (int)cc * 8) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {
-                bf16x8 hi, lo;  // dz is stored S8: staged by copy
-                if constexpr (PASSES >= 3) {
-                    s8_unpack(v[u], hi, lo);
-                    if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + p.dz_plane + dst[u]) = lo;
-                } else {
-                    s8_unpack_hi(v[u], hi);
-                }
-                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
-            }
-        }
-    }
+    // ---- dz image of this sample into LDS (zero border of bt pixels top / left, the rest bottom / right) ----
+    fill_image_s8<GEMM_THREADS, B_PLANES, 8>(img, p.dz_plane, p.dz + (int64_t)j * g.hout * g.wout * g.cout_p, g.hout, g.wout, g.cout_p,
+                                             -p.bt, -p.bt, p.Hd, p.Wd, p.PPd, tid, p.d_chunk, p.d_Wd);
 
     ISDQN_STAMP(1);  // dz image staged (this wave)
     // ---- per-lane pixel of the two column tiles ----
@@ -985,7 +930,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
         p.cls_d_w[cls].divmod((uint32_t)q, a, b);
         const int iy = cy + g.stride * (int)a, ix = cx + g.stride * (int)b;
         pix_iy[nt] = iy; pix_ix[nt] = ix;
-        const int oyb = (iy + g.pad - py) / g.stride, oxb = (ix + g.pad - px) / g.stride;
+        const int oyb = (iy + g.pad - py) >> g.stride_sh, oxb = (ix + g.pad - px) >> g.stride_sh;  // (non-negative multiples of the stride)
         b_org[nt] = ((oyb + p.bt) * p.Wd + oxb + p.bt) * p.PPd;
     }
 
@@ -1223,7 +1168,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
         }
     __syncthreads();
     for (int i = tid; i < 3 * g.cin_p; i += GEMM_THREADS) {
-        const int which = i / g.cin_p, c = i % g.cin_p;
+        const int which = (i >= g.cin_p) + (i >= 2 * g.cin_p), c = i - which * g.cin_p;
         p.part[((int64_t)blockIdx.x * 3 + which) * g.cin_p + c] =
             s_part[0][which][c] + s_part[1][which][c] + s_part[2][which][c] + s_part[3][which][c];
     }

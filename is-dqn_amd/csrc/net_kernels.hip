@@ -1081,6 +1081,7 @@ static ConvGeom conv_geom(const Layer& l) {
     g.hin = l.hin; g.win = l.win; g.cin_p = l.cin_p; g.hout = l.hout; g.wout = l.wout;
     g.cout = l.cout; g.cout_p = l.cout_p; g.ksz = l.ksz; g.stride = l.stride; g.pad = l.pad;
     g.npix = l.npix; g.K = l.K;
+    g.stride_sh = l.stride == 4 ? 2 : l.stride == 2 ? 1 : 0;
     g.d_npix = FastDiv(l.npix); g.d_wout = FastDiv(l.wout); g.d_cinp = FastDiv(l.cin_p);
     g.d_ksz = FastDiv(l.ksz); g.d_coutp = FastDiv(l.cout_p);
     return g;
@@ -1377,6 +1378,7 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
     wp.d_Wp = FastDiv((uint32_t)Wp);
     wp.d_R = FastDiv((uint32_t)wp.R);
     wp.d_dzchunk = FastDiv((uint32_t)(l.cout_p / 8));
+    wp.d_npixpad = FastDiv((uint32_t)wp.npix_pad);
     wp.dz = dz; wp.in = act_in;
     wp.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win, in.id_pitch, in.id_off};
     wp.slabs = slabs;
@@ -1384,6 +1386,7 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
     wp.n_img = n_img; wp.G = l.wgi_G;
     wp.NC = 64 * l.wgi_ntw;
     wp.n_col_groups = l.K / wp.NC;
+    wp.d_ncg = FastDiv((uint32_t)wp.n_col_groups);
     const int groups = ceil_div(n_img, l.wgi_G);
     *slabs_out = groups;
 #define WGI(MT_, NTW_, P_, U_) return launch_conv_wgrad_img<MT_, NTW_, P_, U_>(wp, groups, st)

@@ -387,6 +387,7 @@ struct DenseDgradLN {
 // ---------------------------------------------------------------------------------------------
 struct ConvGeom {
     int hin, win, cin_p, hout, wout, cout, cout_p, ksz, stride, pad, npix, K;
+    int stride_sh;  // log2(stride): the torso's strides are 4, 2, 1 (dqn.py:55-69), divisions by the stride are shifts
     FastDiv d_npix, d_wout, d_cinp, d_ksz, d_coutp;
 };
 
