@@ -244,6 +244,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4000)
     ap.add_argument("--settle", type=int, default=-1, help="untimed steps in front of the warm-up (default: up to 2000 so that warm-up + settle >= 2000)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--K", type=int, default=0, help="override the number of Bellman iterations of the workload (the reference's "
+                    "timing sweep launch_job/atari/launch_time.sh:13-27 runs K in 1, 4, 9, 49)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--capacity", type=int, default=1_000_000)
     ap.add_argument("--graph", type=int, default=8, help="most steps captured per hipGraph (0 = eager launches)")
@@ -274,6 +276,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = f"cuda:{local_rank}"
+    if args.K > 0:
+        WORKLOADS[args.workload] = dict(WORKLOADS[args.workload], K=args.K, desc=WORKLOADS[args.workload]["desc"].replace(
+            f"K={WORKLOADS[args.workload]['K']}", f"K={args.K}"))
     w = WORKLOADS[args.workload]
 
     rep = Replica(args.workload, args.capacity, args.precision, seed=rank, device=device)
@@ -336,7 +341,7 @@ def main():
         achieved = bytes_step / (dev_ms_avg * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(args.workload, args.precision)
         out = {
-            "metric": "gradient-steps/sec (batch=256, K=9, 84x84x4)" if args.workload != "c5" else "gradient-steps/sec (batch=1024, K=32, 84x84x4)",
+            "metric": f"gradient-steps/sec (batch={w['B']}, K={w['K']}, 84x84x4)",
             "value": aggregate_value(world, args.steps, elapsed_max),
             "unit": "gradient-steps/s",
             "n_gpus": world,
