@@ -253,6 +253,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-capacity", type=int, default=1_000_000)
     ap.add_argument("--replay-stats", type=int, default=200, help="graph replays timed one by one after the run (0 = skip)")
+    ap.add_argument("--replicas-per-gpu", type=int, default=1, help="independent replicas sharing each GPU on their own streams, as the "
+                    "reference shares one GPU between seeds (launch_job/atari/normal/train.sh:9-16); the headline number is 1")
     args = ap.parse_args()
     assert args.steps >= 1 and args.warmup >= 0 and args.gpus >= 1
 
@@ -281,16 +283,29 @@ def main():
             f"K={WORKLOADS[args.workload]['K']}", f"K={args.K}"))
     w = WORKLOADS[args.workload]
 
-    rep = Replica(args.workload, args.capacity, args.precision, seed=rank, device=device)
+    R = max(1, args.replicas_per_gpu)
+    reps = [Replica(args.workload, args.capacity, args.precision, seed=rank * R + r, device=device) for r in range(R)]
+    rep = reps[0]
     S = 1
     if args.graph > 0:
         S = steps_per_graph(args.steps, args.warmup, args.graph)
         try:
-            rep.enable_graph(S)
+            for x in reps:
+                x.enable_graph(S)
         except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
-            rep.graphed, S = None, 1
-    one = (lambda: rep.graphed.run()) if rep.graphed is not None else rep.step
+            for x in reps:
+                x.graphed = None
+            S = 1
+    if R == 1:
+        one = (lambda: rep.graphed.run()) if rep.graphed is not None else rep.step
+    else:  # every replica on its own stream: their kernels interleave on the GPU (a "step" below is one step of EVERY replica)
+        streams = [torch.cuda.Stream(device) for _ in reps]
+
+        def one():
+            for x, st in zip(reps, streams):
+                with torch.cuda.stream(st):
+                    x.graphed.run() if x.graphed is not None else x.step()
     settle = args.settle if args.settle >= 0 else max(0, 2000 - args.warmup)
     settle = (settle + S - 1) // S * S
     for _ in range(settle // S):
@@ -335,14 +350,16 @@ def main():
                  "ms_per_step_p90": q(0.9), "note": "each replay bracketed by its own HIP events (adds ~6 us per replay); not the timed region"}
 
     if rank == 0:
-        dev_ms_avg = ev0.elapsed_time(ev1) / args.steps
+        # (several replicas per GPU run on their own streams: the two events bracket only the default stream, so the
+        # device time per replica step is the synchronised wall time of the region)
+        dev_ms_avg = ev0.elapsed_time(ev1) / args.steps if R == 1 else elapsed * 1e3 / (args.steps * R)
         bytes_step = algorithmic_bytes_per_step(w["B"], w["K"], w["n_actions"], w["prioritized"])
         flops_step = algorithmic_flops_per_step(w["B"], w["K"], w["n_actions"])
         achieved = bytes_step / (dev_ms_avg * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(args.workload, args.precision)
         out = {
             "metric": f"gradient-steps/sec (batch={w['B']}, K={w['K']}, 84x84x4)",
-            "value": aggregate_value(world, args.steps, elapsed_max),
+            "value": aggregate_value(world * R, args.steps, elapsed_max),
             "unit": "gradient-steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -355,7 +372,7 @@ def main():
             "dtype": "bf16x3 (split-bf16 MFMA operands hi+lo, fp32 accumulate)" if args.precision == "bf16x3" else "bf16 (single pass, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": w["desc"], "replay_capacity": args.capacity, "precision": args.precision,
-                       "launch": f"hipGraph x{S} steps" if rep.graphed is not None else "eager", "replicas": world, "parallelism": f"independent-seed replicas x{world}"},
+                       "launch": f"hipGraph x{S} steps" if rep.graphed is not None else "eager", "replicas": world * R, "replicas_per_gpu": R, "parallelism": f"independent-seed replicas x{world * R}"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,

@@ -128,6 +128,9 @@ typedef struct isdqn_net_config {
     int32_t precision;                    /* ISDQN_PRECISION_*                                         */
     float gamma_n;                        /* gamma ** update_horizon (isdqn.py:107)                    */
     float learning_rate, adam_b1, adam_b2, adam_eps; /* optax.adam(lr, eps=adam_eps) (isdqn.py:46)    */
+    float huber_delta;                    /* 0: squared TD error, the reference's loss (isdqn.py:102); > 0: Huber loss with
+                                           * this delta (0.5 d^2 for |d| <= delta, delta (|d| - delta/2) beyond; the north
+                                           * star's wording), gradient clip(d, -delta, delta)                */
 } isdqn_net_config;
 
 /* One parameter tensor inside the flat fp32 parameter buffer.  `name` is the Flax

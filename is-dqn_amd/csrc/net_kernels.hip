@@ -324,10 +324,19 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
 // One workgroup per 64 transitions, wave w takes heads k = w, w+4, ...  Emits dL/dq rows (dout),
 // q_values/targets/priorities and per-workgroup partials of the per-head loss sums and of the head
 // bias gradient (column sums of dout); loss_finalize_kernel reduces them in a fixed order.
+// Per-element loss and its derivative w.r.t. q for d = q - target: squared error (the reference, isdqn.py:102) or, with
+// huber_delta > 0, the Huber loss (0.5 d^2 inside, delta (|d| - delta / 2) outside; derivative clip(d, -delta, delta)).
+__device__ __forceinline__ float td_loss(float d, float huber_delta) {
+    const float a = fabsf(d);
+    return huber_delta > 0.f ? (a <= huber_delta ? 0.5f * d * d : huber_delta * (a - 0.5f * huber_delta)) : d * d;
+}
+__device__ __forceinline__ float td_dloss(float d, float huber_delta) {
+    return huber_delta > 0.f ? fminf(fmaxf(d, -huber_delta), huber_delta) : 2.f * d;
+}
 constexpr int TD_ROWS = 64;
 __global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, int B, int K, int oh, int A, int nha_p,
                                                  const int* __restrict__ action, const float* __restrict__ reward,
-                                                 const uint8_t* __restrict__ terminal, float gamma_n,
+                                                 const uint8_t* __restrict__ terminal, float gamma_n, float huber_delta,
                                                  float* __restrict__ dout, float* __restrict__ q_values,
                                                  float* __restrict__ targets, double* __restrict__ priorities,
                                                  float* __restrict__ loss_part, float* __restrict__ dbh_part) {
@@ -360,11 +369,11 @@ __global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, in
             for (int j = 1; j < A; ++j) mx = fmaxf(mx, nq[j]);
             float tg = r + nt * gamma_n * mx;
             d = qv - tg;
-            td = d * d;
+            td = td_loss(d, huber_delta);
             if (q_values) q_values[(int64_t)b * K + k] = qv;
             if (targets) targets[(int64_t)b * K + k] = tg;
         }
-        s_d[lane * K + k] = 2.f * d * inv_b;
+        s_d[lane * K + k] = td_dloss(d, huber_delta) * inv_b;
         s_td[lane * K + k] = td;
         float sum = td;
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
@@ -421,7 +430,7 @@ struct HeadChainParams {
     const int* action;
     const float* reward;
     const uint8_t* terminal;
-    float gamma_n;
+    float gamma_n, huber_delta;
     float* dout;        // [B][Op]  dL/dq
     float* dz;          // [B][Fp]
     float* part;        // [n_wg][3][Fp]
@@ -726,11 +735,11 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
             for (int j = 1; j < A; ++j) mx = fmaxf(mx, nq[j]);
             const float tg = td_r + (1.f - (float)td_term) * p.gamma_n * mx;
             d = qv - tg;
-            td = d * d;
+            td = td_loss(d, p.huber_delta);
             if (p.q_values) p.q_values[(int64_t)b * K + k] = qv;
             if (p.targets) p.targets[(int64_t)b * K + k] = tg;
         }
-        const float dd = 2.f * d * inv_b;
+        const float dd = td_dloss(d, p.huber_delta) * inv_b;
         s_d[tid] = dd;
         s_td[tid] = td;
         s_dq[s * Op + (p.oh + k) * A + a] = dd;
@@ -1718,7 +1727,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         hp.B = B; hp.S = hc_S; hp.F = hid.out_f; hp.Fp = hid.out_p; hp.O = P.nha; hp.Op = P.nha_p; hp.K = K; hp.oh = P.oh;
         hp.A = P.n_actions;
         hp.action = batch->action; hp.reward = batch->reward; hp.terminal = batch->terminal;
-        hp.gamma_n = cfg->gamma_n;
+        hp.gamma_n = cfg->gamma_n; hp.huber_delta = cfg->huber_delta;
         hp.dout = ws + P.dout_off; hp.dz = ws + hid.dz_off; hp.part = ws + hid.part_off;
         hp.q_values = qv; hp.targets = tg; hp.priorities = priorities;
         hp.loss_part = loss_part; hp.dbh_part = dbh_part;
@@ -1755,7 +1764,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         }
     } else {
         hipLaunchKernelGGL(td_kernel, dim3(n_blk), dim3(256), 2 * TD_ROWS * K * sizeof(float), st, ws + P.q_off, B, K,
-                           P.oh, P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n,
+                           P.oh, P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n, cfg->huber_delta,
                            learn ? ws + P.dout_off : nullptr, qv, tg, priorities, loss_part, dbh_part);
         ISDQN_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(ceil_div(K, 16) + ceil_div(P.nha_p, 16)), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p,

@@ -79,6 +79,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
     ISDQN_REQUIRE(cfg->batch_size >= 1 && cfg->batch_size <= 4096, ISDQN_ERR_ARG, "batch_size must be in [1, 4096]");
     ISDQN_REQUIRE(cfg->precision == ISDQN_PRECISION_BF16X3 || cfg->precision == ISDQN_PRECISION_BF16, ISDQN_ERR_ARG,
                   "bad precision");
+    ISDQN_REQUIRE(cfg->huber_delta >= 0.f, ISDQN_ERR_ARG, "huber_delta must be >= 0 (0 = squared error)");
     P.regions.clear();
     P.B = cfg->batch_size;
     P.N2 = 2 * P.B;

@@ -68,6 +68,7 @@ def run(argvs=sys.argv[1:], root=None):
         adam_eps=1.5e-4,
         batch_size=p["batch_size"],
         precision=p["precision"],
+        huber_delta=p["huber_delta"],
     )
     if p["prioritized"]:
         _wire_prioritized(agent, rb)

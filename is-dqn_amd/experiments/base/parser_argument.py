@@ -40,6 +40,7 @@ _TFDQN = [_ISDQN[1], _ISDQN[2], _ISDQN[3]]  # add_tfdqn_arguments: layer_norm, b
 _ENGINE = [
     ("-prec", "--precision", dict(type=str, default="bf16x3", choices=["bf16x3", "bf16"], help="MFMA precision of the HIP engine.")),
     ("-per", "--prioritized", dict(action="store_true", default=False, help="Prioritized replay (sum-tree on the GPU) with TD-error writeback.")),
+    ("-hd", "--huber_delta", dict(type=float, default=0.0, help="0: squared TD error (the reference's loss); > 0: Huber loss with this delta.")),
     ("-env", "--env_backend", dict(type=str, default="ale", choices=["ale", "synthetic"], help="'synthetic' replaces ALE by random frames (no ROMs needed).")),
 ]
 

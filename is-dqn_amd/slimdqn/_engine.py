@@ -35,6 +35,7 @@ class QNetEngine:
         adam_eps: float = 1e-8,
         precision: str = "bf16x3",
         device: str | None = None,
+        huber_delta: float = 0.0,
     ):
         _hip.require_gpu()
         self.lib = _hip.lib()
@@ -65,6 +66,7 @@ class QNetEngine:
         cfg.learning_rate = float(learning_rate)
         cfg.adam_b1, cfg.adam_b2 = 0.9, 0.999
         cfg.adam_eps = float(adam_eps)
+        cfg.huber_delta = float(huber_delta)  # 0: the reference's squared TD error
         self.cfg = cfg
         self.features = feats
         self.architecture_type = architecture_type

@@ -42,6 +42,7 @@ class NetConfig(ctypes.Structure):
         ("adam_b1", c_float),
         ("adam_b2", c_float),
         ("adam_eps", c_float),
+        ("huber_delta", c_float),
     ]
 
 

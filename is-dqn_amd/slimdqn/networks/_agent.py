@@ -34,7 +34,7 @@ class EngineAgent:
     """Common state: ``n_heads`` network heads of ``n_actions`` outputs each on the HIP engine."""
 
     def _init_engine_agent(self, key, observation_dim, n_actions, n_heads, features, layer_norm, architecture_type,
-                           learning_rate, gamma, update_horizon, adam_eps, batch_size, precision, device):
+                           learning_rate, gamma, update_horizon, adam_eps, batch_size, precision, device, huber_delta=0.0):
         self.n_actions = n_actions
         self._n_heads = int(n_heads)
         self.features = [int(f) for f in features]
@@ -46,6 +46,7 @@ class EngineAgent:
         self.gamma = gamma
         self.update_horizon = update_horizon
         self.precision = precision
+        self.huber_delta = float(huber_delta)
         self.device = device
         self._seed = int(key) if not isinstance(key, torch.Generator) else int(key.initial_seed())
         self._engine = None
@@ -58,7 +59,7 @@ class EngineAgent:
         eng = QNetEngine(
             self.observation_dim, self.n_actions, self._n_heads, self.features, self.architecture_type,
             self.layer_norm, batch_size, gamma_n=self.gamma**self.update_horizon, learning_rate=self.learning_rate,
-            adam_eps=self.adam_eps, precision=self.precision, device=self.device,
+            adam_eps=self.adam_eps, precision=self.precision, device=self.device, huber_delta=self.huber_delta,
         )
         if init:
             eng.init_params(self._seed)

@@ -46,7 +46,9 @@ class iSDQN(EngineAgent):
         precision: str = "bf16x3",
         device: str | None = None,
         use_graph: bool = True,
+        huber_delta: float = 0.0,
     ):
+        """``huber_delta``: 0 keeps the reference's squared TD error (isdqn.py:102); > 0 trains on the Huber loss."""
         if batch_norm:
             raise NotImplementedError("BatchNorm variants are outside the hot-path scope (SURVEY.md section 8)")
         self.n_bellman_iterations = n_bellman_iterations
@@ -59,7 +61,7 @@ class iSDQN(EngineAgent):
         self.use_graph = bool(use_graph)
         self.priority_writeback = False
         self._init_engine_agent(key, observation_dim, n_actions, 1 + n_bellman_iterations, features, layer_norm, architecture_type,
-                                learning_rate, gamma, update_horizon, adam_eps, batch_size, precision, device)
+                                learning_rate, gamma, update_horizon, adam_eps, batch_size, precision, device, huber_delta)
         self._action_rng = np.random.default_rng(self._seed + 1)
         self.cumulated_losses = np.zeros(self.n_bellman_iterations)
 

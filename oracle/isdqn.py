@@ -43,7 +43,11 @@ class iSDQN:
         adam_eps: float = 1e-8,
         dtype=torch.float32,
         params=None,
+        huber_delta: float = 0.0,
     ):
+        """``huber_delta``: 0 = the reference's squared TD error (isdqn.py:102); > 0 = Huber loss (optax.huber_loss: 0.5 d^2 for
+        |d| <= delta, delta (|d| - delta / 2) beyond) -- the north star's wording, not in the reference."""
+        self.huber_delta = float(huber_delta)
         assert not batch_norm, "BatchNorm variants are out of the hot-path scope (SURVEY.md section 8)"
         self.n_bellman_iterations = n_bellman_iterations
         self.n_actions = n_actions
@@ -116,7 +120,12 @@ class iSDQN:
         all_q = self.apply(params, torch.cat((state, next_state)))  # (2B, 1+K, A)
         q_values = all_q[:B, 1:].gather(2, action.view(B, 1, 1).expand(B, self.n_bellman_iterations, 1)).squeeze(2)
         targets = self.compute_target(reward[:, None], terminal[:, None], all_q[B:, :-1]).detach()
-        td = (q_values - targets) ** 2
+        d = q_values - targets
+        if self.huber_delta > 0:
+            a = d.abs()
+            td = torch.where(a <= self.huber_delta, 0.5 * d * d, self.huber_delta * (a - 0.5 * self.huber_delta))
+        else:
+            td = d**2
         return q_values, targets, td
 
     def loss_on_batch(self, params, samples):

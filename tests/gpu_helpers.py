@@ -64,7 +64,7 @@ def device_batch(eng, frames, ids, action, reward, terminal):
     return batch
 
 
-def masked_reference_grads(params, feats, K, A, ref, z_hip, layer_norm=True, gamma_n=0.99):
+def masked_reference_grads(params, feats, K, A, ref, z_hip, layer_norm=True, gamma_n=0.99, huber_delta=0.0):
     """float64 torch gradients of the iS-DQN loss (isdqn.py:92-109) in which every ReLU of the ONLINE half takes its
     pass/block decision from the HIP path's own pre-activations `z_hip[layer]` ([B, ...] float32, layer names Conv_0..2,
     Dense_0).  Why: a batch holds 10^5..10^7 ReLU inputs, a few of them within the forward's 1e-5 of zero; where the HIP
@@ -117,6 +117,11 @@ def masked_reference_grads(params, feats, K, A, ref, z_hip, layer_norm=True, gam
     r = torch.tensor(np.asarray(ref.reward, np.float64))
     t = torch.tensor(np.asarray(ref.is_terminal, np.float64))
     tg = r[:, None] + (1 - t)[:, None] * gamma_n * q[B:, :K].max(-1).values
-    loss = ((qv - tg.detach()) ** 2).mean(0).sum()
+    d = qv - tg.detach()
+    if huber_delta > 0:
+        td = torch.where(d.abs() <= huber_delta, 0.5 * d * d, huber_delta * (d.abs() - 0.5 * huber_delta))
+    else:
+        td = d**2
+    loss = td.mean(0).sum()
     loss.backward()
     return {m: {k: v.grad.numpy() for k, v in d.items()} for m, d in P.items()}

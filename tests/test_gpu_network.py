@@ -218,6 +218,52 @@ def test_forward_loss_grad_adam(cfg, precision):
     assert int(eng.adam_count.item()) == 3
 
 
+@pytest.mark.parametrize("delta", [0.25, 1.0])
+def test_huber_loss_option_matches_the_oracle(delta):
+    """cfg.huber_delta > 0 (include/isdqn_hip.h): Huber loss instead of the reference's squared TD error -- losses, priorities
+    and the first-step gradients against the oracle with the same option, through both learn paths (head chain at B = 8,
+    td_kernel in loss_on_batch)."""
+    from oracle.isdqn import iSDQN as OracleAgent
+    from slimdqn._engine import QNetEngine
+    from tests.gpu_helpers import perturbed_params
+
+    feats, K, A, B = (32, 64, 64, 512), 3, 5, 8
+    params = perturbed_params(3, (84, 84, 4), feats, "cnn", (1 + K) * A, True)
+    oracle = OracleAgent(3, (84, 84, 4), A, K, list(feats), True, False, "cnn", 1e-3, 0.99, 1, 1, 1, adam_eps=1.5e-4, params=params, huber_delta=delta)
+    eng = QNetEngine((84, 84, 4), A, 1 + K, feats, "cnn", True, B, gamma_n=0.99, learning_rate=1e-3, adam_eps=1.5e-4, huber_delta=delta)
+    eng.import_flax(params)
+    frames, ids, action, reward, terminal, ref = make_frame_batch(B, A, seed=11)
+    reward = (3.0 * reward).astype(np.float32)  # TD errors on both sides of delta
+    ref = ref.__class__(state=ref.state, action=ref.action, reward=reward.astype(np.float64), next_state=ref.next_state, is_terminal=ref.is_terminal)
+    batch = device_batch(eng, frames, ids, action, reward, terminal)
+    o_q, o_t, o_td = oracle.loss_terms(oracle.params, ref)
+    d = (o_q - o_t).abs()
+    assert (d > delta).any() and (d < delta).any()
+    pre = eng.loss_on_batch(batch).cpu().numpy().copy()
+    assert np.abs(pre - o_td.mean(0).detach().numpy()).max() < 1e-3 * max(1.0, float(o_td.mean(0).max()))
+    o_grads, _ = oracle.grads(oracle.params, ref)
+    grad = torch.zeros_like(eng.params)
+    losses = eng.learn_on_batch(batch, grad_out=grad).cpu().numpy()
+    assert np.abs(losses - o_td.mean(0).detach().numpy()).max() < 1e-3 * max(1.0, float(o_td.mean(0).max()))
+    exp = np.sqrt(o_td.detach().numpy().mean(1) + 1e-10)
+    assert np.abs(eng.priorities.cpu().numpy() - exp).max() < 1e-2 * max(1.0, exp.max())
+    # gradients against the float64 reference with the HIP path's own ReLU decisions (see test_large_batch_kernel_variants)
+    z_hip = {}
+    for n in ("Conv_0", "Conv_1", "Conv_2", "Dense_0"):
+        width, c = _z_width(eng, n)
+        z_hip[n] = eng.region("z/" + n).cpu().numpy()[: B * width].reshape(B, -1, (c + 7) // 8 * 8)[:, :, :c].reshape(B, -1)
+    m_grads = masked_reference_grads(params, feats, K, A, ref, z_hip, layer_norm=True, gamma_n=0.99, huber_delta=delta)
+    g = eng.internal_to_flax_grads(grad)
+    for mod in m_grads:
+        for leaf in m_grads[mod]:
+            e = _flat_err(g[mod][leaf], m_grads[mod][leaf])
+            assert e < 1e-4, f"grad {mod}/{leaf}: rel err {e} against the mask-pinned reference"
+    for mod in o_grads:  # and the independent oracle, Euclidean (a ReLU decision may differ: 1/B of a leaf)
+        for leaf in o_grads[mod]:
+            a, b = np.asarray(g[mod][leaf], np.float64), o_grads[mod][leaf].numpy().astype(np.float64)
+            assert np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12) < 10 * TOL["bf16x3"]["grad"], f"grad {mod}/{leaf} vs oracle"
+
+
 def test_shift_and_best_action():
     feats, K, A, B = (7, 9, 11, 13), 4, 6, 4
     oracle, eng, params = make_pair(feats, K, A, B, seed=5)

@@ -66,3 +66,22 @@ def test_adam_step_moves_every_parameter_by_about_lr_on_the_first_step():
             moved = (p1[m][n] - t.params[m][n]).abs()
             nz = g[m][n].abs() > 1e-4
             assert torch.allclose(moved[nz], torch.full_like(moved[nz], 1e-3), rtol=1e-3)
+
+
+def test_huber_option_of_the_isdqn_oracle_matches_torch_and_reduces_to_l2_scale():
+    """The Huber option (north-star wording; the reference trains on the squared error, isdqn.py:102): per-element values equal
+    torch's huber_loss, the gradient w.r.t. q is clip(d, -delta, delta) / B, and huber_delta = 0 is the reference's loss."""
+    import torch.nn.functional as F
+
+    from oracle.isdqn import iSDQN
+
+    K, A, B = 3, 4, 6
+    l2 = iSDQN(2, (84, 84, 4), A, K, FEATS, True, False, "cnn", 1e-3, 0.99, 1, 1, 1, dtype=torch.float64)
+    hub = iSDQN(2, (84, 84, 4), A, K, FEATS, True, False, "cnn", 1e-3, 0.99, 1, 1, 1, dtype=torch.float64, huber_delta=0.25)
+    s = _batch(B, A, seed=6)
+    q, t, td2 = l2.loss_terms(l2.params, s)
+    qh, th, tdh = hub.loss_terms(hub.params, s)
+    assert torch.allclose(q, qh) and torch.allclose(t, th)
+    assert torch.allclose(td2, (q - t) ** 2)
+    assert torch.allclose(tdh, F.huber_loss(qh, th, reduction="none", delta=0.25), rtol=1e-12, atol=1e-15)
+    assert ((q - t).abs() > 0.25).any() and ((q - t).abs() < 0.25).any()  # both branches are exercised
