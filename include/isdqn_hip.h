@@ -230,6 +230,13 @@ int isdqn_net_best_action(const isdqn_net_config* cfg, const float* params, cons
                           int64_t frame_stride, const int32_t* frame_ids, const float* obs, int32_t idx_network,
                           int32_t* out_action, void* workspace, void* stream);
 
+/* best_action for `n_rows` observations at once (vectorised host environments: one forward, one argmax launch):
+ * out_actions[i] = argmax_a of online head idx_networks[i] (device int32 arrays) of observation i.  n_rows <= 2 * batch_size.
+ * flags: ISDQN_BATCH_MIRROR_CURRENT when the caller knows the workspace's weight mirror matches `params`. */
+int isdqn_net_best_actions(const isdqn_net_config* cfg, const float* params, const uint8_t* frames, int64_t frame_stride,
+                           const int32_t* frame_ids, const float* obs, int32_t n_rows, const int32_t* idx_networks,
+                           int32_t* out_actions, int32_t flags, void* workspace, void* stream);
+
 /* Engine self-test: C[M][N] = A . B on the MFMA tile engine for every operand-layout
  * combination (a_tr/b_tr: 0 = operand stored [rows][K], 1 = stored [K][rows]).  Test hook. */
 int isdqn_selftest_gemm(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t a_tr,

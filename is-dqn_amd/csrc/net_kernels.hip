@@ -1047,6 +1047,20 @@ __global__ void argmax_kernel(const float* __restrict__ q, int A, int head, int*
     }
 }
 
+// batched form: row i -> first argmax of head oh + idx[i] of its own q row
+__global__ __launch_bounds__(64) void argmax_rows_kernel(const float* __restrict__ q, int n_rows, int nha_p, int A, int oh, int K,
+                                                         const int* __restrict__ idx, int* __restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_rows) return;
+    int head = idx[i];
+    head = oh + (head < 0 ? 0 : head >= K ? K - 1 : head);
+    const float* r = q + (int64_t)i * nha_p + head * A;
+    int best = 0;
+    for (int a = 1; a < A; ++a)
+        if (r[a] > r[best]) best = a;
+    out[i] = best;
+}
+
 // =============================================================================================
 // Host orchestration
 // =============================================================================================
@@ -2069,6 +2083,35 @@ extern "C" int isdqn_net_best_action(const isdqn_net_config* cfg, const float* p
     rc = net_forward(P, cfg->precision == ISDQN_PRECISION_BF16X3, params, in, 1, 0, ws, ws + P.q_off, st);
     if (rc) return rc;
     hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(64), 0, st, ws + P.q_off, P.n_actions, P.oh + idx_network, out_action);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
+// best_action for n observations in one forward (vectorised environments: n host envs, one launch chain), with the
+// "weight mirror is current" promise of ISDQN_BATCH_MIRROR_CURRENT as a flag.
+extern "C" int isdqn_net_best_actions(const isdqn_net_config* cfg, const float* params, const uint8_t* frames,
+                                      int64_t frame_stride, const int32_t* frame_ids, const float* obs, int32_t n_rows,
+                                      const int32_t* idx_networks, int32_t* out_actions, int32_t flags, void* workspace,
+                                      void* stream) {
+    int rc;
+    const Plan* Pp = cached_plan(cfg, &rc);
+    if (!Pp) return rc;
+    const Plan& P = *Pp;
+    ISDQN_REQUIRE(params && idx_networks && out_actions && workspace, ISDQN_ERR_ARG, "null pointer");
+    ISDQN_REQUIRE(n_rows >= 1 && n_rows <= P.N2, ISDQN_ERR_SHAPE, "n_rows must be in [1, 2 * batch_size] (workspace rows)");
+    rc = check_input(cfg, frames, frame_stride, frame_ids, obs);
+    if (rc) return rc;
+    NetInput in{frames, frame_stride, frame_ids, 0, obs, nullptr, 0};
+    float* ws = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    if (!(flags & ISDQN_BATCH_MIRROR_CURRENT)) {
+        rc = refresh_mirror(P, params, ws, st);
+        if (rc) return rc;
+    }
+    rc = net_forward(P, cfg->precision == ISDQN_PRECISION_BF16X3, params, in, n_rows, 0, ws, ws + P.q_off, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, st, ws + P.q_off, n_rows, P.nha_p, P.n_actions,
+                       P.oh, P.K, idx_networks, out_actions);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
 }

@@ -32,11 +32,17 @@ def run(argvs=sys.argv[1:], root=None):
     if p["env_backend"] == "synthetic":
         from slimdqn.environments.synthetic import SyntheticAtariEnv
 
-        env = SyntheticAtariEnv(game, seed=p["seed"])
+        make_env = lambda i: SyntheticAtariEnv(game, seed=p["seed"] + 1000 * i)
     else:
         from slimdqn.environments.atari import AtariEnv
 
-        env = AtariEnv(game)
+        make_env = lambda i: AtariEnv(game)
+    if p["n_envs"] > 1:  # not in the reference: n host environments acted on with one batched forward per round
+        from slimdqn.environments.vector import VectorEnv
+
+        env = VectorEnv([make_env(i) for i in range(p["n_envs"])])
+    else:
+        env = make_env(0)
     if p["prioritized"]:
         sampler = PrioritizedSamplingDistribution(p["seed"], p["replay_buffer_capacity"])
     else:
@@ -84,7 +90,7 @@ def _wire_prioritized(agent, rb):
     (samplers.py MAX_PRIORITY), the write-back is part of the captured step (networks/isdqn.py)."""
     sampler = rb._sampling_distribution
     plain_add = rb.add
-    rb.add = lambda transition, **kw: plain_add(transition, priority=kw.get("priority", sampler.MAX_PRIORITY))
+    rb.add = lambda transition, **kw: plain_add(transition, **{"priority": sampler.MAX_PRIORITY, **kw})
     agent.priority_writeback = True
 
 

@@ -32,11 +32,17 @@ def run(argvs=sys.argv[1:], root=None):
     if p["env_backend"] == "synthetic":
         from slimdqn.environments.synthetic import SyntheticAtariEnv
 
-        env = SyntheticAtariEnv(game, seed=p["seed"])
+        make_env = lambda i: SyntheticAtariEnv(game, seed=p["seed"] + 1000 * i)
     else:
         from slimdqn.environments.atari import AtariEnv
 
-        env = AtariEnv(game)
+        make_env = lambda i: AtariEnv(game)
+    if p["n_envs"] > 1:
+        from slimdqn.environments.vector import VectorEnv
+
+        env = VectorEnv([make_env(i) for i in range(p["n_envs"])])
+    else:
+        env = make_env(0)
     sampler = UniformSamplingDistribution(p["seed"])
     rb = ReplayBuffer(
         sampling_distribution=sampler,

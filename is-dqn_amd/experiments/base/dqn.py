@@ -16,7 +16,7 @@ import numpy as np
 
 from experiments.base import dist as replicas
 from experiments.base.utils import save_data
-from slimdqn.sample_collection.utils import collect_single_sample, linear_schedule
+from slimdqn.sample_collection.utils import collect_single_sample, collect_vector_samples, linear_schedule
 
 EPOCH_FIELDS = ("avg_return", "avg_length_episode", "n_training_steps", "env_steps_per_s")
 
@@ -36,10 +36,35 @@ def train(key, p: dict, agent, env, rb):
     best_avg_return = -float("inf")
     gathered = []
 
+    vector = hasattr(env, "envs")  # VectorEnv: n environments per round, same per-step cadence of the updates
+    run_return, run_length = ([0.0] * len(env), [0] * len(env)) if vector else (None, None)
+
+    def after_step():
+        if n_training_steps > p["n_initial_samples"]:
+            agent.update_online_params(n_training_steps, rb)
+            updated, logs = agent.update_target_params(n_training_steps)
+            if updated:
+                p["wandb"].log({"n_training_steps": n_training_steps, **logs})
+
     for idx_epoch in range(p["n_epochs"]):
         steps_in_epoch, has_reset = 0, False
         t_epoch = time.perf_counter()
+        if vector:
+            returns[idx_epoch], lengths[idx_epoch] = [], []  # finished episodes of this epoch, any environment
         while steps_in_epoch < p["n_training_steps_per_epoch"] or not has_reset:
+            if vector:
+                for i, (reward, ended) in enumerate(collect_vector_samples(rng, env, agent, rb, p, epsilon_schedule, n_training_steps)):
+                    steps_in_epoch += 1
+                    n_training_steps += 1
+                    run_return[i] += reward
+                    run_length[i] += 1
+                    if ended:
+                        returns[idx_epoch].append(run_return[i])
+                        lengths[idx_epoch].append(run_length[i])
+                        run_return[i], run_length[i] = 0.0, 0
+                        has_reset = True
+                    after_step()
+                continue
             reward, has_reset = collect_single_sample(rng, env, agent, rb, p, epsilon_schedule, n_training_steps)
             steps_in_epoch += 1
             n_training_steps += 1
@@ -48,11 +73,7 @@ def train(key, p: dict, agent, env, rb):
             if has_reset and steps_in_epoch < p["n_training_steps_per_epoch"]:
                 returns[idx_epoch].append(0)
                 lengths[idx_epoch].append(0)
-            if n_training_steps > p["n_initial_samples"]:
-                agent.update_online_params(n_training_steps, rb)
-                updated, logs = agent.update_target_params(n_training_steps)
-                if updated:
-                    p["wandb"].log({"n_training_steps": n_training_steps, **logs})
+            after_step()
 
         avg_return = float(np.mean(returns[idx_epoch]))
         avg_length = float(np.mean(lengths[idx_epoch]))

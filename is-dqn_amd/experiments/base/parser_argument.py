@@ -41,6 +41,7 @@ _ENGINE = [
     ("-prec", "--precision", dict(type=str, default="bf16x3", choices=["bf16x3", "bf16"], help="MFMA precision of the HIP engine.")),
     ("-per", "--prioritized", dict(action="store_true", default=False, help="Prioritized replay (sum-tree on the GPU) with TD-error writeback.")),
     ("-hd", "--huber_delta", dict(type=float, default=0.0, help="0: squared TD error (the reference's loss); > 0: Huber loss with this delta.")),
+    ("-nenvs", "--n_envs", dict(type=int, default=1, help="Host environments stepped in lockstep with one batched best_actions forward (1 = the reference's loop).")),
     ("-env", "--env_backend", dict(type=str, default="ale", choices=["ale", "synthetic"], help="'synthetic' replaces ALE by random frames (no ROMs needed).")),
 ]
 

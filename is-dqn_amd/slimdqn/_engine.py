@@ -244,6 +244,7 @@ class QNetEngine:
             ),
             "isdqn_net_forward",
         )
+        self._mirror_holds(params)
         return q
 
     def learn_on_batch(self, batch: _hip.Batch, grad_out: torch.Tensor | None = None) -> torch.Tensor:
@@ -258,6 +259,7 @@ class QNetEngine:
         else:
             rc = self.lib.isdqn_net_learn_on_batch_debug(*args, _hip.ptr(grad_out))
         _hip.check(rc, "isdqn_net_learn_on_batch")
+        self._mirror_made_current()  # Adam wrote the updated weights in both forms
         return self.losses
 
     def learn_on_batch_target(self, batch: _hip.Batch, target_params: torch.Tensor) -> torch.Tensor:
@@ -271,6 +273,7 @@ class QNetEngine:
             ),
             "isdqn_net_learn_on_batch_target",
         )
+        self._mirror_made_current()
         return self.losses
 
     def loss_on_batch_target(self, batch: _hip.Batch, target_params: torch.Tensor, params=None) -> torch.Tensor:
@@ -282,6 +285,7 @@ class QNetEngine:
             ),
             "isdqn_net_loss_on_batch_target",
         )
+        self._mirror_holds(params)
         return self.losses
 
     def loss_on_batch(self, batch: _hip.Batch, params=None) -> torch.Tensor:
@@ -293,11 +297,13 @@ class QNetEngine:
             ),
             "isdqn_net_loss_on_batch",
         )
+        self._mirror_holds(params)
         return self.losses
 
     def shift_params(self, params=None) -> None:
         p = self.params if params is None else params
         _hip.check(self.lib.isdqn_net_shift_params(ctypes.byref(self.cfg), _hip.ptr(p), _hip.stream_ptr(self.device)))
+        self._mirror_version = None  # the head rows moved in the master only
 
     def best_action(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, idx_network: int, params=None) -> torch.Tensor:
         p = self.params if params is None else params
@@ -308,7 +314,38 @@ class QNetEngine:
             ),
             "isdqn_net_best_action",
         )
+        self._mirror_holds(params)
         return self.action_out
+
+    # ------------------------------------------------------------------ weight-mirror bookkeeping (acting path)
+    # The library keeps a pre-split mirror of the weights in the workspace and rebuilds it at the head of every call unless
+    # told that it is current.  learn_on_batch leaves it current; any torch-side in-place write to `self.params` bumps the
+    # tensor's version counter, a head shift goes through `shift_params` -- both invalidate.
+    def _mirror_is_current(self, params) -> bool:
+        return params is None and getattr(self, "_mirror_version", None) == self.params._version
+
+    def _mirror_made_current(self) -> None:
+        self._mirror_version = self.params._version
+
+    def _mirror_holds(self, params) -> None:
+        """The call just enqueued rebuilt the mirror from `params` (None = the engine's own buffer)."""
+        self._mirror_version = self.params._version if params is None else None
+
+    def best_actions(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, idx_networks: torch.Tensor, params=None) -> torch.Tensor:
+        """Greedy actions of n observations in one forward (isdqn.py:127-135 per row): int32 device tensor [n]."""
+        n = int(idx_networks.numel())
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        p = self.params if params is None else params
+        flags = _hip.BATCH_MIRROR_CURRENT if self._mirror_is_current(params) else 0
+        _hip.check(
+            self.lib.isdqn_net_best_actions(
+                ctypes.byref(self.cfg), _hip.ptr(p), _hip.ptr(frames), int(frame_stride), _hip.ptr(frame_ids), _hip.ptr(obs), n,
+                _hip.ptr(idx_networks), _hip.ptr(out), flags, _hip.ptr(self.workspace), _hip.stream_ptr(self.device),
+            ),
+            "isdqn_net_best_actions",
+        )
+        self._mirror_holds(params)
+        return out
 
     def internal_to_flax_grads(self, grad_flat: torch.Tensor) -> Dict[str, Dict[str, np.ndarray]]:
         return self.export_flax(grad_flat)

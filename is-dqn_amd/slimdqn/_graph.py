@@ -119,3 +119,4 @@ class GraphedUpdate:
         rows = sampler.draw_rows_device(self.S, self.B)
         self.block.copy_(rows, non_blocking=True)
         self.graph.replay()
+        self.eng._mirror_made_current()  # the last step's optimizer wrote both forms of the weights

@@ -128,6 +128,10 @@ _SIGNATURES = {
         c_int32,
         [POINTER(NetConfig), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p],
     ),
+    "isdqn_net_best_actions": (
+        c_int32,
+        [POINTER(NetConfig), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
+    ),
     "isdqn_selftest_gemm": (
         c_int32,
         [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],

@@ -30,6 +30,15 @@ class DeviceParams:
     copy = clone  # the reference's ``self.params.copy()`` (dqn.py:34, 50)
 
 
+def _is_one_frame_shift(old: np.ndarray, new: np.ndarray) -> bool:
+    """new[..., :-1] == old[..., 1:] for (h, w, stack) uint8 stacks.  stack == 4: one pixel's frames are one little-endian
+    uint32, so the test is a shift and a mask over contiguous words (a few us; the strided comparison costs ~70 us)."""
+    if old.shape[-1] == 4 and old.flags.c_contiguous and new.flags.c_contiguous:
+        o, n = old.reshape(-1).view("<u4"), new.reshape(-1).view("<u4")
+        return bool(np.array_equal(n & np.uint32(0x00FFFFFF), o >> np.uint32(8)))
+    return bool(np.array_equal(new[..., :-1], old[..., 1:]))
+
+
 class EngineAgent:
     """Common state: ``n_heads`` network heads of ``n_actions`` outputs each on the HIP engine."""
 
@@ -51,6 +60,7 @@ class EngineAgent:
         self._seed = int(key) if not isinstance(key, torch.Generator) else int(key.initial_seed())
         self._engine = None
         self._graphed = None
+        self._ring = None  # device copy of the acting path's frame stack (see _obs_to_device)
         self._make_engine(batch_size, init=True)
 
     # ------------------------------------------------------------------ engine management
@@ -71,6 +81,7 @@ class EngineAgent:
             eng.losses_accum.copy_(old.losses_accum)
         self._engine = eng
         self._graphed = None  # captured against the old engine's buffers
+        self._ring = None
         self.params = DeviceParams(eng, eng.params)
         self.optimizer_state = {"count": eng.adam_count, "mu": eng.adam_m, "nu": eng.adam_v}
         self._engine_changed(old)
@@ -130,13 +141,58 @@ class EngineAgent:
             obs = torch.as_tensor(np.asarray(state, dtype=np.float32)).reshape(1, -1).to(eng.device)
             return dict(obs=obs)
         s = np.asarray(state)
+        s = s.astype(np.uint8) if s.dtype != np.uint8 else s.copy()
         h, w, stack = s.shape
-        planes = np.ascontiguousarray(np.moveaxis(s, -1, 0)).reshape(stack, h * w)
-        if planes.dtype != np.uint8:
-            planes = planes.astype(np.uint8)
-        fr = torch.from_numpy(planes).to(eng.device)
-        ids = torch.arange(stack, dtype=torch.int32, device=eng.device)
-        return dict(frames=fr, frame_stride=h * w, frame_ids=ids)
+        ring = self._ring
+        if ring is None or ring["last"].shape != s.shape:
+            rot = (torch.arange(stack)[None, :] + torch.arange(stack)[:, None]) % stack
+            ring = self._ring = dict(
+                planes=torch.empty(stack, h * w, dtype=torch.uint8, device=eng.device),
+                rot=rot.to(torch.int32).to(eng.device),  # row r: plane slots oldest..newest after r one-frame shifts
+                shifts=0,
+                last=None,
+            )
+        # Consecutive acting states differ by one frame (atari.py:71-78 rolls the stack): the device keeps the stack as a
+        # ring of planes and only the newest 7 KB frame crosses PCIe; anything else (reset, a foreign state) is a full upload.
+        if ring["last"] is not None and _is_one_frame_shift(ring["last"], s):
+            slot = ring["shifts"] % stack  # the oldest plane's slot
+            ring["planes"][slot].copy_(torch.from_numpy(np.ascontiguousarray(s[..., -1]).reshape(-1)))
+            ring["shifts"] += 1
+        else:
+            ring["planes"].copy_(torch.from_numpy(np.ascontiguousarray(np.moveaxis(s, -1, 0)).reshape(stack, h * w)))
+            ring["shifts"] = 0
+        ring["last"] = s
+        return dict(frames=ring["planes"], frame_stride=h * w, frame_ids=ring["rot"][ring["shifts"] % stack])
+
+    def _states_to_device(self, states):
+        """n observations (n, h, w, stack) or (n, d) -> planes / rows for one batched forward."""
+        eng = self._engine
+        if self.architecture_type == "fc":
+            s = np.asarray(states, dtype=np.float32)
+            return dict(obs=torch.from_numpy(s.reshape(s.shape[0], -1)).to(eng.device))
+        s = np.asarray(states)
+        s = s.astype(np.uint8) if s.dtype != np.uint8 else s
+        n, h, w, stack = s.shape
+        planes = torch.from_numpy(np.ascontiguousarray(np.moveaxis(s, -1, 1)).reshape(n * stack, h * w)).to(eng.device)
+        ids = torch.arange(n * stack, dtype=torch.int32, device=eng.device)
+        return dict(frames=planes, frame_stride=h * w, frame_ids=ids)
+
+    def _best_action(self, params, state, idx_network: int) -> int:
+        """One observation: newest frame up, one forward (weight mirror reused when nothing wrote the parameters since the
+        last learn step), one 4-byte read back."""
+        eng = self._engine
+        heads = getattr(self, "_head_ids", None)
+        if heads is None or heads.device != eng.device:
+            heads = self._head_ids = torch.arange(max(self._n_heads, 1), dtype=torch.int32, device=eng.device)
+        out = eng.best_actions(idx_networks=heads[idx_network : idx_network + 1], params=self._bind(params), **self._obs_to_device(state))
+        return int(out.item())
+
+    def _best_actions(self, params, states, idx_networks) -> np.ndarray:
+        """Greedy actions of n observations in one forward and one device->host copy."""
+        eng = self._engine
+        idx = torch.as_tensor(np.asarray(idx_networks, dtype=np.int32)).to(eng.device)
+        out = eng.best_actions(idx_networks=idx, params=self._bind(params), **self._states_to_device(states))
+        return out.cpu().numpy()
 
     def _q_row(self, params, state) -> torch.Tensor:
         """network.apply on one observation: device row of n_heads * n_actions values."""

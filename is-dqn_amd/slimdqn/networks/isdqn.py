@@ -150,5 +150,16 @@ class iSDQN(EngineAgent):
             idx = int(key)
         else:
             idx = int(key.integers(0, self.n_bellman_iterations))
-        out = self._engine.best_action(idx_network=idx, params=self._bind(params), **self._obs_to_device(state))
-        return int(out.item())
+        return self._best_action(params, state, idx)
+
+    def best_actions(self, params, states, key=None) -> np.ndarray:
+        """``best_action`` for n observations (vectorised host environments): one head draw per observation from ``key``
+        (None: the agent's generator; an int array: the heads themselves), one forward, one read back."""
+        n = len(states)
+        if key is None:
+            idx = self._action_rng.integers(0, self.n_bellman_iterations, size=n)
+        elif isinstance(key, np.random.Generator):
+            idx = key.integers(0, self.n_bellman_iterations, size=n)
+        else:
+            idx = np.broadcast_to(np.asarray(key), (n,))
+        return self._best_actions(params, states, idx)

@@ -82,5 +82,7 @@ class TFDQN(EngineAgent):
         return self._q_row(params, state).cpu().numpy().reshape(self.n_actions)
 
     def best_action(self, params, state, **kwargs):
-        out = self._engine.best_action(idx_network=0, params=self._bind(params), **self._obs_to_device(state))
-        return int(out.item())
+        return self._best_action(params, state, 0)
+
+    def best_actions(self, params, states, **kwargs) -> np.ndarray:
+        return self._best_actions(params, states, np.zeros(len(states), dtype=np.int32))

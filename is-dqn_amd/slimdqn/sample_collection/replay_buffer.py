@@ -174,6 +174,7 @@ class ReplayBuffer:
         self._gamma = gamma
         self._clipping = clipping
         self._trajectory = collections.deque()  # entries: (frame_slot, action, reward, is_terminal)
+        self._trajectories = {0: self._trajectory}  # one n-step accumulator per transition stream (vectorised envs)
         self._traj_maxlen = update_horizon + stack_size
         self._memory = _MemoryView(self)
         self._frames = None
@@ -319,7 +320,13 @@ class ReplayBuffer:
         self._h_index_to_slot[index] = key % self._max_capacity
         self._dirty_index.append(index)
 
-    def add(self, transition: TransitionElement, **kwargs: Any) -> None:
+    def add(self, transition: TransitionElement, stream: int = 0, **kwargs: Any) -> None:
+        """replay_buffer.py:185-196.  ``stream``: which environment of a vectorised collector the transition comes from --
+        each stream has its own trajectory accumulator (frame stacks and n-step returns never mix environments), all of them
+        feed the same element table in arrival order."""
+        if stream not in self._trajectories:
+            self._trajectories[stream] = collections.deque()
+        self._trajectory = self._trajectories[stream]
         sampler = self._sampling_distribution
         C = self._max_capacity
         for ids, action, reward, is_terminal in self.accumulate(transition):

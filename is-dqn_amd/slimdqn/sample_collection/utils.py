@@ -43,3 +43,39 @@ def collect_single_sample(key, env, agent, rb: ReplayBuffer, p, epsilon_schedule
     if episode_end:
         env.reset()
     return reward, episode_end
+
+
+def collect_vector_samples(key, venv, agent, rb: ReplayBuffer, p, epsilon_schedule, n_training_steps: int):
+    """One round of ``collect_single_sample`` over the n environments of a VectorEnv: the epsilon draws per environment as in
+    ``select_action``, ONE batched forward for the greedy ones, then every environment steps and adds to its own stream
+    of the replay buffer.  Returns [(reward, episode_end)] in environment order."""
+    n = len(venv)
+    actions = np.empty(n, dtype=np.int64)
+    greedy = []
+    for i in range(n):
+        if key.random() <= epsilon_schedule(n_training_steps + i):
+            actions[i] = key.integers(0, venv.n_actions)
+        else:
+            greedy.append(i)
+    if greedy:
+        states = np.stack([np.asarray(venv.envs[i].state).astype(np.uint8, copy=False) for i in greedy])
+        actions[greedy] = agent.best_actions(agent.params, states, key=key)
+    out = []
+    for i, env in enumerate(venv.envs):
+        obs = env.observation
+        reward, absorbing = env.step(int(actions[i]))
+        episode_end = absorbing or env.n_steps >= p["horizon"]
+        rb.add(
+            TransitionElement(
+                observation=obs,
+                action=int(actions[i]),
+                reward=reward if rb._clipping is None else rb._clipping(reward),
+                is_terminal=absorbing,
+                episode_end=episode_end,
+            ),
+            stream=i,
+        )
+        if episode_end:
+            env.reset()
+        out.append((reward, episode_end))
+    return out

@@ -113,6 +113,102 @@ def test_best_action_follows_head_choice():
     assert 0 <= hip.best_action(hip.params, state) < A
 
 
+def test_acting_path_frame_ring_and_weight_mirror_reuse():
+    """The acting path keeps the frame stack on the device as a ring (one 7 KB frame uploaded per step) and reuses the
+    workspace's pre-split weights while nothing has written the parameters: both must be invisible -- every action equals
+    the argmax of a fresh full forward, across rolls, a reset, a learn step, a torch-side parameter write and a head shift."""
+    from slimdqn._engine import QNetEngine
+    from slimdqn.environments.synthetic import SyntheticAtariEnv
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+
+    K, A, B = 3, 5, 8
+    hip, _ = _agents(K, A, B)
+    eng = hip._engine
+    # the checker: a second engine (own workspace, own weight mirror) run on the agent's parameter buffer
+    chk = QNetEngine((84, 84, 4), A, 1 + K, FEATS, "cnn", True, B, gamma_n=0.99, learning_rate=2e-4, adam_eps=1.5e-4)
+    env = SyntheticAtariEnv("Synthetic", n_actions=A, seed=3, episode_length=9)
+    env.reset()
+    rb = ReplayBuffer(UniformSamplingDistribution(3), B, 100, update_horizon=1, gamma=0.99)
+    rng = np.random.default_rng(0)
+    reused = fulls = 0
+    for t in range(40):
+        state = env.state
+        idx = t % K
+        shifts_before = None if hip._ring is None else hip._ring["shifts"]
+        was_current = eng._mirror_is_current(None)
+        action = hip.best_action(hip.params, state, key=idx)
+        reused += was_current
+        fulls += hip._ring["shifts"] == 0
+        q = chk.forward(n_rows=1, params=eng.params, **_planes(state, eng.device)).cpu().numpy().reshape(1 + K, A)
+        assert action == int(np.argmax(q[1 + idx])), t
+        obs = env.observation
+        reward, terminal = env.step(action)
+        rb.add(TransitionElement(obs, action, reward, terminal, terminal))
+        if terminal:
+            env.reset()
+        if t >= 12 and t % 4 == 0:
+            hip.update_online_params(t, rb)  # data_to_update = 2: a learn step
+        if t == 25:
+            eng.params.mul_(1.01)  # a torch-side write: the mirror must be rebuilt
+            assert not eng._mirror_is_current(None)
+        if t == 30:
+            hip.shift_params(hip.params)
+            assert not eng._mirror_is_current(None)
+    assert reused >= 20 and 3 <= fulls <= 8  # most steps reuse the mirror; full uploads only at episode starts
+
+
+def _planes(state, device):
+    s = np.asarray(state).astype(np.uint8)
+    h, w, stack = s.shape
+    fr = torch.from_numpy(np.ascontiguousarray(np.moveaxis(s, -1, 0)).reshape(stack, h * w)).to(device)
+    return dict(frames=fr, frame_stride=h * w, frame_ids=torch.arange(stack, dtype=torch.int32, device=device))
+
+
+def test_batched_best_actions_match_single_and_oracle():
+    K, A, B = 3, 5, 8
+    hip, ora = _agents(K, A, B)
+    rng = np.random.default_rng(7)
+    n = 2 * B  # the most rows one workspace takes
+    states = rng.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8)
+    heads = rng.integers(0, K, n)
+    got = hip.best_actions(hip.params, states, key=heads)
+    assert got.shape == (n,) and got.dtype == np.int32
+    for i in range(n):
+        assert got[i] == hip.best_action(hip.params, states[i], key=int(heads[i]))
+        assert got[i] == ora.best_action(ora.params, states[i], int(heads[i]))
+    same_stream = hip.best_actions(hip.params, states, key=np.random.default_rng(1))
+    np.testing.assert_array_equal(same_stream, hip.best_actions(hip.params, states, key=np.random.default_rng(1).integers(0, K, n)))
+    with pytest.raises(AssertionError):  # ISDQN_ERR_SHAPE: more rows than the workspace holds
+        hip.best_actions(hip.params, np.zeros((2 * B + 1, 84, 84, 4), np.uint8), key=0)
+
+
+def test_vector_collection_round():
+    """collect_vector_samples: one batched forward for the greedy environments, every transition into its own stream."""
+    from slimdqn.environments.synthetic import SyntheticAtariEnv
+    from slimdqn.environments.vector import VectorEnv
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+    from slimdqn.sample_collection.utils import collect_vector_samples
+
+    K, A, B = 3, 5, 8
+    hip, _ = _agents(K, A, B)
+    venv = VectorEnv([SyntheticAtariEnv("Synthetic", n_actions=A, seed=10 + i, episode_length=7 + i) for i in range(4)])
+    venv.reset()
+    assert venv.states.shape == (4, 84, 84, 4) and venv.states.dtype == np.uint8
+    rb = ReplayBuffer(UniformSamplingDistribution(3), B, 500, update_horizon=3, gamma=0.99)
+    rng = np.random.default_rng(0)
+    ends = 0
+    for t in range(30):
+        out = collect_vector_samples(rng, venv, hip, rb, {"horizon": 1000}, lambda step: 0.3, 4 * t)
+        assert len(out) == 4
+        ends += sum(e for _, e in out)
+    assert ends >= 8 and len(rb._trajectories) == 4
+    assert rb.add_count > 80
+    batch = rb.sample()
+    assert batch.state.shape == (B, 84, 84, 4)
+
+
 @pytest.mark.parametrize("prioritized", [False, True])
 def test_entry_point_end_to_end_on_synthetic_env(tmp_path, prioritized):
     from experiments.atari.isdqn import run
@@ -132,3 +228,16 @@ def test_entry_point_end_to_end_on_synthetic_env(tmp_path, prioritized):
     assert model["params"]["Dense_1"]["kernel"].shape == (16, 3 * 9)
     with pytest.raises(AssertionError):  # same seed again: refused (experiments/base/utils.py:46-51)
         run(argv, root=str(tmp_path))
+
+
+def test_entry_point_with_vectorised_environments(tmp_path):
+    from experiments.atari.isdqn import run
+
+    argv = ["-en", "vec_Synthetic", "-s", "1", "-dw", "-f", "8", "8", "8", "16", "-rbc", "300", "-bs", "8", "-n", "3", "-horizon", "40",
+            "-at", "cnn", "-ne", "2", "-ntspe", "90", "-utd", "4", "-nis", "30", "-ed", "100", "-nbi", "2", "-ln", "-tuf", "16",
+            "-env", "synthetic", "-nenvs", "3", "-per"]
+    gathered = run(argv, root=str(tmp_path))
+    assert len(gathered) == 2 and gathered[0].shape == (1, 4)
+    res = json.load(open(tmp_path / "atari" / "exp_output" / "vec_Synthetic" / "isdqn" / "episode_returns_and_lengths" / "1.json"))
+    assert len(res["episode_returns"]) == 2 and all(len(r) >= 1 for r in res["episode_returns"])
+    assert all(l == 40 for epoch in res["episode_lengths"] for l in epoch)  # horizon-truncated episodes, whole ones only

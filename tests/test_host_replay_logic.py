@@ -129,3 +129,41 @@ def test_prefetched_draws_stay_on_the_reference_stream():
         elif r < 0.12:  # different batch size once in a while
             np.testing.assert_array_equal(a.sample(5), b.sample(5))
     assert a._pf is not None and a._pf["n"] in (1, 64)
+
+
+def test_streams_keep_their_own_trajectories():
+    """Vectorised collection (`add(..., stream=i)`): the elements of each stream are exactly those a buffer fed by that stream
+    alone produces (frame stacks and n-step returns never mix environments), interleaved in arrival order."""
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+
+    n_streams, n, stack = 3, 3, 4
+    rb = ReplayBuffer(UniformSamplingDistribution(0, device="cpu"), 8, 10_000, stack_size=stack, update_horizon=n, gamma=0.9, device="cpu")
+    alone = [OracleRB(OracleUniform(0), 8, 10_000, stack_size=stack, update_horizon=n, gamma=0.9) for _ in range(n_streams)]
+    rng = np.random.default_rng(5)
+    origin = []  # element key of the shared buffer -> (stream, key in that stream's own buffer)
+    for t in range(200):
+        for i in range(n_streams):
+            obs = rng.integers(0, 256, (6, 5), dtype=np.uint8)
+            action, reward = int(rng.integers(0, 5)), float(rng.normal())
+            terminal = bool(rng.random() < 0.08)
+            end = terminal or bool(rng.random() < 0.05)
+            before = alone[i].add_count
+            rb.add(TransitionElement(obs, action, reward, terminal, end), stream=i)
+            alone[i].add(OT(obs, action, reward, terminal, end))
+            origin += [(i, k) for k in range(before, alone[i].add_count)]
+    assert rb.add_count == len(origin) == sum(o.add_count for o in alone)
+    for key, (i, k) in enumerate(origin):
+        a, b = rb._memory[key], alone[i]._memory[k]
+        np.testing.assert_array_equal(a.state, b.state)
+        np.testing.assert_array_equal(a.next_state, b.next_state)
+        assert (a.action, a.reward, bool(a.is_terminal)) == (b.action, b.reward, bool(b.is_terminal))
+    held = np.zeros_like(rb._refcount)
+    for key in rb._memory.keys():
+        for f in rb._h_elem_frames[key % 10_000]:
+            if f >= 0:
+                held[f] += 1
+    for traj in rb._trajectories.values():
+        for entry in traj:
+            held[entry[0]] += 1
+    np.testing.assert_array_equal(held, rb._refcount)
