@@ -175,6 +175,9 @@ typedef struct isdqn_batch {
     const float* reward;      /* [B]  n-step discounted reward                                 */
     const uint8_t* terminal;  /* [B]                                                           */
     int32_t flags;            /* ISDQN_BATCH_* (0 when in doubt)                               */
+    void* priorities_ready;   /* hipEvent_t or NULL: recorded on `stream` once q_values / targets / priorities / losses of
+                               * this call are final (long before the call's last kernel), so that a caller's second stream
+                               * can write the priorities back (R6) and draw the next batch (S4, R5) under the backward pass */
 } isdqn_batch;
 
 /* The workspace keeps a pre-split (bf16 hi + lo) mirror of the weights that the MFMA stages copy from.  Every entry point

@@ -1786,18 +1786,42 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                            cfg->adam_b1, cfg->adam_b2, adam_consts);
         ISDQN_HIP_CHECK(hipGetLastError());
     }
+    // q_values / targets / priorities / per-head loss partials are final here.  The caller's event (batch->priorities_ready) is
+    // recorded at the first point that forks the caller's stream anyway (every fork costs it a dependency bubble), else now.
+    bool prio_pending = batch->priorities_ready != nullptr;
+    auto signal_priorities = [&]() -> int {
+        if (prio_pending) {
+            prio_pending = false;
+            ISDQN_HIP_CHECK(hipEventRecord((hipEvent_t)batch->priorities_ready, st));
+        }
+        return ISDQN_OK;
+    };
+    if (!learn || !ss) {
+        rc = signal_priorities();
+        if (rc) return rc;
+    }
     if (!learn) return ISDQN_OK;
 
     // ---- backward (online rows only: the next-state half has a zero cotangent, isdqn.py:99) ----
-    AdamTable tab;
-    tab.n = 0;
-    int blocks = 0;
-    auto add_entry = [&](int64_t p_off, int64_t size, const float* g, int n_slabs, int64_t stride) {
+    // Two optimizer tables: tensors whose gradient is produced on the weight-gradient stream are updated there, the others on
+    // the caller's stream, so the step ends with two short Adam launches side by side instead of join -> reduce -> one Adam.
+    AdamTable tabs[2];  // [0] caller's stream, [1] weight-gradient stream
+    tabs[0].n = tabs[1].n = 0;
+    tabs[0].total_blocks = tabs[1].total_blocks = 0;
+    auto add_entry_on = [&](int which, int64_t p_off, int64_t size, const float* g, int n_slabs, int64_t stride) {
+        AdamTable& tab = tabs[which];
         AdamEntry& e = tab.e[tab.n++];
         e.p_off = p_off; e.size = size; e.g = g; e.n_slabs = n_slabs; e.slab_stride = stride;
-        e.block_start = blocks;
-        blocks += (int)((size + 63) / 64);
+        e.block_start = tab.total_blocks;
+        tab.total_blocks += (int)((size + 63) / 64);
     };
+    auto add_entry = [&](int64_t p_off, int64_t size, const float* g, int n_slabs, int64_t stride) {
+        add_entry_on(0, p_off, size, g, n_slabs, stride);
+    };
+    // With a weight-gradient stream and at least three layers, the last two weight gradients swap streams: layer 1's follows
+    // its data gradient on the caller's stream, layer 0's (which only needs that data gradient's output) runs beside it.
+    const bool tail_swap = ss && P.n_layers >= 3 && !P.L[1].is_head;
+    bool forked = false, layer0_chained = false;
     const float* dz_cur = ws + P.dout_off;  // gradient w.r.t. the current layer's pre-activation output
     int dz_ld = P.nha_p;
     bool dz_fused = false;  // dz of layer i was already produced by the fused data gradient of layer i+1
@@ -1847,18 +1871,21 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 add_entry(l.b_off, l.out_p, ws + l.part_off + 2 * l.out_p, nb, 3 * (int64_t)l.out_p);
             }
         } else {
-            add_entry(l.b_off, l.out_p, ws + P.dbh_off, 1, 0);
+            add_entry_on(hc_S && ss ? 1 : 0, l.b_off, l.out_p, ws + P.dbh_off, 1, 0);  // loss_finalize_kernel's stream
         }
         // Weight gradients of the middle layers go to the side stream.  Every fork costs the main stream an event
         // record (a ~6 us bubble), so the head's tiny weight gradient and the first layer's (nothing is left to
         // overlap with) stay on the main stream, and a layer whose Adam is fused forks once, after its data gradient.
         const bool head_chained = l.is_head && hc_S;  // the fork happened right after the head chain
-        const bool wg_on_side = ss && !l.is_head && i > 0;
+        const bool wg_on_side = ss && !l.is_head && (tail_swap ? i != 1 : i > 0);
         hipStream_t lws = (wg_on_side || head_chained) ? wst : st;
-        const bool fork_after_dgrad = wg_on_side && l.kind == 1;
-        if (wg_on_side && !fork_after_dgrad) {  // dz of this layer is final on the main stream
+        const bool fork_after_dgrad = wg_on_side && l.kind == 1 && i > 0;
+        if (wg_on_side && !fork_after_dgrad && !(i == 0 && layer0_chained)) {  // dz of this layer is final on the main stream
             rc = chain(ss, st, lws);
             if (rc) return rc;
+            rc = signal_priorities();
+            if (rc) return rc;
+            forked = true;
             rc = run_head_deferred(lws);
             if (rc) return rc;
         }
@@ -1931,13 +1958,23 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         if (fork_after_dgrad) {  // dz is final AND the data gradient (which reads W) is enqueued: an in-place
             rc = chain(ss, st, lws);  // fused-Adam update on the side stream cannot overtake it
             if (rc) return rc;
+            rc = signal_priorities();
+            if (rc) return rc;
+            forked = true;
             rc = run_head_deferred(lws);
+            if (rc) return rc;
+        }
+        if (tail_swap && i == 1 && dz_fused) {  // layer 0's dz is final: its weight gradient may start beside this layer's
+            rc = chain(ss, st, wst);
+            if (rc) return rc;
+            forked = layer0_chained = true;
+            rc = run_head_deferred(wst);
             if (rc) return rc;
         }
         int w_slabs;
         bool fused_adam = false;
         if (head_chained && ss) {  // enqueued by run_head_deferred()
-            add_entry(l.w_off, l.w_size, ws + l.gw_off, effective_splits(B, l.gw_slabs), l.w_size);
+            add_entry_on(1, l.w_off, l.w_size, ws + l.gw_off, effective_splits(B, l.gw_slabs), l.w_size);
             continue;
         }
         if (l.kind == 0) {
@@ -1990,14 +2027,28 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
             }
         }
         if (rc) return rc;
-        if (!fused_adam) add_entry(l.w_off, l.w_size, ws + l.gw_off, w_slabs, l.w_size);
+        if (!fused_adam) add_entry_on(lws == wst && ss ? 1 : 0, l.w_off, l.w_size, ws + l.gw_off, w_slabs, l.w_size);
     }
-    tab.total_blocks = blocks;
     if (head_deferred) {  // no layer forked: keep the two kernels in line
         rc = run_head_deferred(st);
         if (rc) return rc;
     }
-    if (ss) {  // all weight gradients done before Adam (and before the next call touches the workspace)
+    rc = signal_priorities();
+    if (rc) return rc;
+    auto run_adam = [&](const AdamTable& tab, hipStream_t s2) -> int {
+        if (tab.n == 0) return ISDQN_OK;
+        hipLaunchKernelGGL(adam_kernel, dim3(tab.total_blocks), dim3(256), 0, s2, tab, params, adam_m, adam_v, ws + P.adam_tab_off,
+                           cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps, grad_out, ws + P.wsplit_off);
+        ISDQN_HIP_CHECK(hipGetLastError());
+        return ISDQN_OK;
+    };
+    // The weight-gradient stream may update its own tensors only when every reader of the weights is behind it: with the
+    // tail swap its last kernel (layer 0's weight gradient) waited for the last data gradient of the caller's stream.
+    const bool adam_on_side = ss && forked && tail_swap;
+    if (adam_on_side) {
+        rc = run_adam(tabs[1], wst);
+        if (rc) return rc;
+    } else if (ss) {  // all weight gradients done before Adam
         rc = chain(ss, wst, st);
         if (rc) return rc;
     }
@@ -2005,9 +2056,15 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(red_jobs.block_start[red_jobs.n]), dim3(256), 0, st, red_jobs);
         ISDQN_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, tab, params, adam_m, adam_v, ws + P.adam_tab_off,
-                       cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps, grad_out, ws + P.wsplit_off);
-    ISDQN_HIP_CHECK(hipGetLastError());
+    rc = run_adam(tabs[0], st);
+    if (rc) return rc;
+    if (adam_on_side) {  // the call is complete on the caller's stream (and the next call may touch the workspace)
+        rc = chain(ss, wst, st);
+        if (rc) return rc;
+    } else {
+        rc = run_adam(tabs[1], st);
+        if (rc) return rc;
+    }
     return ISDQN_OK;
 }
 

@@ -216,11 +216,14 @@ class QNetEngine:
 
     # ------------------------------------------------------------------ C-ABI calls
     def make_batch(self, *, frames=None, frame_stride=0, frame_ids=None, state=None, next_state=None, action=None, reward=None, terminal=None,
-                   mirror_current: bool = False) -> _hip.Batch:
+                   mirror_current: bool = False, priorities_ready: torch.cuda.Event | None = None) -> _hip.Batch:
         """``mirror_current``: promise that the previous call on this engine was learn_on_batch and nothing wrote the
-        parameters since (include/isdqn_hip.h, ISDQN_BATCH_MIRROR_CURRENT) -- only the captured multi-step graphs do."""
+        parameters since (include/isdqn_hip.h, ISDQN_BATCH_MIRROR_CURRENT) -- only the captured multi-step graphs do.
+        ``priorities_ready``: an event (already recorded once, so that its handle exists) the learn call records on the
+        caller's stream as soon as q_values / targets / priorities are final."""
         b = _hip.Batch()
         b.flags = _hip.BATCH_MIRROR_CURRENT if mirror_current else 0
+        b.priorities_ready = None if priorities_ready is None else int(priorities_ready.cuda_event)
         b.B = self.batch_size
         b.frames = _hip.ptr(frames)
         b.frame_stride = int(frame_stride)
@@ -231,7 +234,7 @@ class QNetEngine:
         b.reward = _hip.ptr(reward)
         b.terminal = _hip.ptr(terminal)
         # keep the tensors alive for the duration of the asynchronous call
-        b._keep = (frames, frame_ids, state, next_state, action, reward, terminal)
+        b._keep = (frames, frame_ids, state, next_state, action, reward, terminal, priorities_ready)
         return b
 
     def forward(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, n_rows: int, params=None) -> torch.Tensor:

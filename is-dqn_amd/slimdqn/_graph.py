@@ -30,7 +30,15 @@ class GraphedUpdate:
         # row gathers are ONE launch over S*B rows at the head of the graph (one 6 us kernel at the head of a step
         # less); every step then has its own static batch.  Prioritized sampling depends on the previous step's
         # priority write-back and keeps one gather per step into a single batch.
-        n_b = 1 if prioritized else self.S
+        # Prioritized: two batch slots alternate, because the write-back of step s and the draw + gather of step s+1 run on a
+        # second stream under the backward pass of step s (learn_on_batch records `priorities_ready` for it).
+        n_b = 2 if prioritized else self.S
+        if prioritized:
+            self.indices = torch.zeros(2, B, dtype=torch.int32, device=dev)
+            self._sampling_stream = torch.cuda.Stream(dev)
+            self._prio_ready = [torch.cuda.Event() for _ in range(2)]
+            for e in self._prio_ready:
+                e.record(self._sampling_stream)  # creates the handle the C ABI takes
         self.frame_ids = torch.zeros(n_b, B, s2, dtype=torch.int32, device=dev)
         self.action = torch.zeros(n_b, B, dtype=torch.int32, device=dev)
         self.reward = torch.zeros(n_b, B, dtype=torch.float32, device=dev)
@@ -44,14 +52,15 @@ class GraphedUpdate:
         rb, eng = self.rb, self.eng
         # steps 2..S of a replay follow a learn step of the same graph directly: the weight mirror is current (the first
         # step of a replay rebuilds it: anything may have written the parameters between two replays)
+        ev = lambda i: self._prio_ready[i] if self.prioritized else None
         self.batches = [
             eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids[i], action=self.action[i],
-                           reward=self.reward[i], terminal=self.terminal[i])
+                           reward=self.reward[i], terminal=self.terminal[i], priorities_ready=ev(i))
             for i in range(self.frame_ids.shape[0])
         ]
         self.chained = [
             eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids[i], action=self.action[i],
-                           reward=self.reward[i], terminal=self.terminal[i], mirror_current=True)
+                           reward=self.reward[i], terminal=self.terminal[i], mirror_current=True, priorities_ready=ev(i))
             for i in range(self.frame_ids.shape[0])
         ]
 
@@ -72,12 +81,22 @@ class GraphedUpdate:
         rb, eng = self.rb, self.eng
         if self.prioritized:
             tree = rb._sampling_distribution._sum_tree
+            main, sampling = torch.cuda.current_stream(eng.device), self._sampling_stream
+            tree.query_device(self.block[0], out=self.indices[0], unit=True)
+            self._gather(self.indices[0], self.B, 0)
             for s in range(self.S):
-                tree.query_device(self.block[s], out=self.indices, unit=True)
-                self._gather(self.indices, self.B, 0)
-                eng.learn_on_batch(self.batches[0] if s == 0 else self.chained[0])
-                if self.writeback:
-                    rb._sampling_distribution.update_device(self.indices, eng.priorities)
+                slot = s & 1
+                eng.learn_on_batch(self.batches[slot] if s == 0 else self.chained[slot])
+                # under the rest of this step (backward, Adam): priorities of step s into the tree, then the draw and the row
+                # gather of step s+1 -- the order the reference's loop has (update, then sample)
+                sampling.wait_event(self._prio_ready[slot])
+                with torch.cuda.stream(sampling):
+                    if self.writeback:
+                        rb._sampling_distribution.update_device(self.indices[slot], eng.priorities)
+                    if s + 1 < self.S:
+                        tree.query_device(self.block[s + 1], out=self.indices[1 - slot], unit=True)
+                        self._gather(self.indices[1 - slot], self.B, 1 - slot)
+                main.wait_stream(sampling)
         else:
             self._gather(self.block, self.S * self.B, 0)  # rows of all S steps: the [S][B] buffers are contiguous
             for s in range(self.S):

@@ -71,6 +71,7 @@ class Batch(ctypes.Structure):
         ("reward", c_void_p),
         ("terminal", c_void_p),
         ("flags", c_int32),
+        ("priorities_ready", c_void_p),
     ]
 
 
