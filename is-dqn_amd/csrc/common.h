@@ -67,6 +67,25 @@ struct FastDiv {
 #define ISDQN_DEV_ENV(name) (false)
 #endif
 
+// Development builds: with ISDQN_DEBUG_OCCUPANCY set, print once per kernel how many workgroups per CU the runtime co-schedules
+// and the grid it was launched with.
+#if defined(ISDQN_DEV)
+#define ISDQN_REPORT_OCCUPANCY(kernel, threads, lds_bytes, grid)                                                              \
+    do {                                                                                                                      \
+        static bool reported_ = false;                                                                                        \
+        if (!reported_ && getenv("ISDQN_DEBUG_OCCUPANCY")) {                                                                  \
+            reported_ = true;                                                                                                 \
+            int nb_ = 0;                                                                                                      \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, reinterpret_cast<const void*>(kernel), (threads),          \
+                                                             (lds_bytes)) == hipSuccess)                                      \
+                fprintf(stderr, "[isdqn] %s: grid %d x %d threads, %d B LDS -> %d workgroups per CU\n", __PRETTY_FUNCTION__,  \
+                        (int)(grid), (int)(threads), (int)(lds_bytes), nb_);                                                  \
+        }                                                                                                                     \
+    } while (0)
+#else
+#define ISDQN_REPORT_OCCUPANCY(kernel, threads, lds_bytes, grid) do {} while (0)
+#endif
+
 // Process-level state of the library is keyed by HIP device: the ">64 KB of LDS" function attribute is per device, and so
 // are the weight-gradient side stream and its events.
 constexpr int ISDQN_MAX_DEVICES = 16;

@@ -124,6 +124,57 @@ __device__ __forceinline__ void fill_image_s8(__bf16* img, int plane_elems, cons
     }
 }
 
+// uint8 frames -> the planar bf16 LDS image img[c][lr][Wp] (zero border included), 8 columns per chunk.
+// Position-major: a thread owns (row, chunk-of-8-columns) positions and walks the `stack` planes of each, so the divisions,
+// the border tests and the in-frame offset are computed once per position instead of once per chunk -- with four workgroups
+// per CU filling at the same time this index arithmetic (integer multiplies are quarter rate), not the loads, was the cost
+// of the fill.  All loads of a batch are issued before the first one is converted.
+template <int NTHR, int STACK_MAX = 4>
+__device__ __forceinline__ void fill_frames_u8(__bf16* img, const FrameSrc& fs, int j, int row_base, int x0, int R, int Wp, int tid,
+                                               const FastDiv& d_cpr) {
+    constexpr int PB = 2;  // positions per thread and batch: PB * stack loads in flight
+    const int cpr = Wp / 8, per_plane = R * cpr, plane = R * Wp;
+    const uint8_t* base[STACK_MAX];
+#pragma unroll
+    for (int c = 0; c < STACK_MAX; ++c) {
+        const int id = c < fs.stack ? fs.frame_id(j, c) : -1;
+        base[c] = id >= 0 ? fs.frames + (int64_t)id * fs.stride : nullptr;
+    }
+    const uint8_t* zeros = reinterpret_cast<const uint8_t*>(zero_chunk());
+    for (int pb = 0; pb < per_plane; pb += NTHR * PB) {
+        unsigned long long raw[PB][STACK_MAX];
+        int sh[PB], dst[PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) {  // loads only: nothing here touches the loaded registers
+            const int pos = pb + k * NTHR + tid;
+            const bool on = pos < per_plane;
+            uint32_t lr, cx;
+            d_cpr.divmod((uint32_t)(on ? pos : 0), lr, cx);
+            const int iy = row_base + (int)lr, ix0 = (int)cx * 8 + x0;
+            const bool ok = on && iy >= 0 && iy < fs.H && ix0 > -8 && ix0 < fs.W;
+            const int ixc = min(max(ix0, 0), fs.W - 8);
+            const int off = iy * fs.W + ixc;
+            sh[k] = ix0 - ixc;
+            dst[k] = on ? (int)lr * Wp + (int)cx * 8 : -1;
+#pragma unroll
+            for (int c = 0; c < STACK_MAX; ++c)
+                raw[k][c] = load_u64_unaligned((ok && base[c] != nullptr) ? base[c] + off : zeros);
+        }
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+#pragma unroll
+            for (int c = 0; c < STACK_MAX; ++c) {
+                if (c >= fs.stack) continue;
+                float v[8];
+                FrameSrc::patch8_cvt(raw[k][c], sh[k], v);
+                bf16x8 hi;
+                round8(v, hi);
+                if (dst[k] >= 0) *reinterpret_cast<bf16x8*>(img + c * plane + dst[k]) = hi;
+            }
+    }
+}
+
+
 // Four waves; each owns all MT channel tiles of 32 output pixels.  (An eight-wave variant -- two waves per SIMD sharing
 // the image, channel halves per wave -- was measured slower: barrier-locked waves do not overlap each other.)
 // The uint8 first layer (MT = 2: 2048 workgroups of 38 KB LDS at the headline size) is asked to fit four workgroups per
@@ -238,38 +289,14 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
     constexpr int FILL_BATCH = (U8 ? 8 : 12) / KG;  // chunks in flight per thread: the 21x21x32 image (10.6 chunks) in ONE round trip
     if (ISDQN_ABLATED(1)) {
     } else if constexpr (U8) {
-        // planar: img[c][lr][Wp], chunk = 8 consecutive padded columns
-        const int cpr = p.Wp / 8;                       // chunks per row (Wp is a multiple of 8)
-        const int n_chunks = p.fs.stack * p.R * cpr;
-        int fid[4] = {-1, -1, -1, -1};                  // id-table lookups hoisted out of the fill
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < p.fs.stack) fid[c] = p.fs.frame_id(j, c);
-        for (int cb = 0; cb < n_chunks; cb += NTHR_ALL * FILL_BATCH) {
-            unsigned long long raw[FILL_BATCH];
-            int sh[FILL_BATCH], dst[FILL_BATCH];
-#pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {  // loads only: nothing here touches the loaded registers
-                const int c0 = cb + u * NTHR_ALL + tid_all;
-                const bool on = c0 < n_chunks;
-                const int cq = on ? c0 : 0;
-                uint32_t cx, rest, lr, c;
-                p.d_chunk.divmod((uint32_t)cq, rest, cx);
-                p.d_R.divmod(rest, c, lr);
-                // (stack <= 4 on this path, host-checked: an id lookup here would put a vmcnt(0) between the frame loads)
-                const int id = c >= 3 ? fid[3] : c == 2 ? fid[2] : c == 1 ? fid[1] : fid[0];
-                p.fs.patch8_raw(on ? id : -1, row_base + (int)lr, (int)cx * 8 - g.pad, raw[u], sh[u]);
-                dst[u] = on ? (((int)c * p.R + (int)lr) * p.Wp + (int)cx * 8) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {
-                float v[8];
-                FrameSrc::patch8_cvt(raw[u], sh[u], v);
-                bf16x8 hi;
-                round8(v, hi);
-                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
-            }
-        }
+#if defined(ISDQN_DEV)
+        if (ISDQN_ABLATED(32)) {  // experiment: no id-table hop (frame slots j*stack + c; wrong results, same traffic)
+            FrameSrc direct = p.fs;
+            direct.ids = nullptr;
+            fill_frames_u8<NTHR_ALL>(img, direct, j, row_base, -g.pad, p.R, p.Wp, tid_all, p.d_chunk);
+        } else
+#endif
+        fill_frames_u8<NTHR_ALL>(img, p.fs, j, row_base, -g.pad, p.R, p.Wp, tid_all, p.d_chunk);
     } else {
         // channel-last: img[lr][xp][PP], chunk = 8 channels of one padded pixel
         fill_image_s8<NTHR_ALL, T::B_PLANES, FILL_BATCH>(img, p.plane_elems, p.in + (int64_t)j * g.hin * g.win * g.cin_p, g.hin, g.win,
@@ -554,6 +581,7 @@ static int launch_conv_fwd_img(const ConvImgParams& p, hipStream_t st) {
     const int lds = (KG * 2 * T::A_STAGE + T::B_PLANES * p.plane_elems) * 2;
     static LdsConfigured configured;
     if (int rc = ensure_dynamic_lds(&conv_fwd_img_kernel<MT, PASSES, U8, KG>, lds, configured)) return rc;
+    ISDQN_REPORT_OCCUPANCY((&conv_fwd_img_kernel<MT, PASSES, U8, KG>), GEMM_THREADS * KG, lds, p.n_img * p.tiles_per_img);
     hipLaunchKernelGGL((conv_fwd_img_kernel<MT, PASSES, U8, KG>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS * KG), lds,
                        st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
@@ -611,36 +639,7 @@ __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, c
                                                  const FastDiv& d_chunk, const FastDiv& d_Wp, const FastDiv& d_R) {
     constexpr int FILL_BATCH = 8;
     if constexpr (U8) {
-        const int cpr = Wp / 8;
-        const int n_chunks = fs.stack * R * cpr;
-        int fid[4] = {-1, -1, -1, -1};
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < fs.stack) fid[c] = fs.frame_id(j, c);
-        for (int cb = 0; cb < n_chunks; cb += NTHR * FILL_BATCH) {
-            unsigned long long raw[FILL_BATCH];
-            int sh[FILL_BATCH], dst[FILL_BATCH];
-#pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {  // loads only: nothing here touches the loaded registers
-                const int c0 = cb + u * NTHR + tid;
-                const bool on = c0 < n_chunks;
-                const int cq = on ? c0 : 0;
-                uint32_t cx, rest, lr, c;
-                d_chunk.divmod((uint32_t)cq, rest, cx);
-                d_R.divmod(rest, c, lr);
-                const int id = c >= 3 ? fid[3] : c == 2 ? fid[2] : c == 1 ? fid[1] : fid[0];  // stack <= 4 (host-checked)
-                fs.patch8_raw(on ? id : -1, row_base + (int)lr, (int)cx * 8 - g.pad, raw[u], sh[u]);
-                dst[u] = on ? (((int)c * R + (int)lr) * Wp + (int)cx * 8) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < FILL_BATCH; ++u) {
-                float v[8];
-                FrameSrc::patch8_cvt(raw[u], sh[u], v);
-                bf16x8 hi;
-                round8(v, hi);
-                if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + dst[u]) = hi;
-            }
-        }
+        fill_frames_u8<NTHR>(img, fs, j, row_base, -g.pad, R, Wp, tid, d_chunk);
     } else {
         fill_image_s8<NTHR, (PASSES >= 3 ? 2 : 1), FILL_BATCH>(img, plane_elems, in + (int64_t)j * g.hin * g.win * g.cin_p, g.hin, g.win, g.cin_p,
                                                                row_base, -g.pad, R, Wp, g.cin_p, tid, d_chunk, d_Wp);
@@ -764,6 +763,7 @@ static int launch_conv_wgrad_img(const ConvWgradImgParams& p, int n_img_groups, 
     const int lds = (A_PLANES * p.dz_plane + B_PLANES * p.in_plane) * 2;
     static LdsConfigured configured;
     if (int rc = ensure_dynamic_lds(&conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>, lds, configured)) return rc;
+    ISDQN_REPORT_OCCUPANCY((&conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>), 64 * WV, lds, n_img_groups * p.n_col_groups);
     hipLaunchKernelGGL((conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>), dim3(n_img_groups * p.n_col_groups),
                        dim3(64 * WV), lds, st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
@@ -1235,6 +1235,7 @@ static int launch_conv_dgrad_img(const ConvDgradImgParams& p, hipStream_t st) {
     const int lds = (2 * A_PLANES * GA::ELEMS + B_PLANES * p.dz_plane) * 2;
     static LdsConfigured configured;
     if (int rc = ensure_dynamic_lds(&conv_dgrad_img_kernel<MT, PASSES>, lds, configured)) return rc;
+    ISDQN_REPORT_OCCUPANCY((&conv_dgrad_img_kernel<MT, PASSES>), GEMM_THREADS, lds, p.n_img * p.tiles_per_img);
     hipLaunchKernelGGL((conv_dgrad_img_kernel<MT, PASSES>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS), lds, st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;

@@ -416,17 +416,7 @@ static int launch_gemm(const P& p, int n_blocks, hipStream_t stream) {
     static LdsConfigured configured;
     int rc = ensure_dynamic_lds(&gemm_kernel<P>, T::LDS_BYTES, configured);
     if (rc) return rc;
-#if defined(ISDQN_DEV)
-    static bool reported = false;
-    if (!reported && getenv("ISDQN_DEBUG_OCCUPANCY")) {  // workgroups per CU the runtime will co-schedule
-        reported = true;
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&gemm_kernel<P>),
-                                                         GEMM_THREADS * T::KG, T::LDS_BYTES) == hipSuccess)
-            fprintf(stderr, "[isdqn] %s: %d threads, %d B LDS -> %d workgroups per CU\n", __PRETTY_FUNCTION__,
-                    GEMM_THREADS * T::KG, T::LDS_BYTES, nb);
-    }
-#endif
+    ISDQN_REPORT_OCCUPANCY((&gemm_kernel<P>), GEMM_THREADS * T::KG, T::LDS_BYTES, n_blocks);
     if (n_blocks <= 0) return ISDQN_OK;
     hipLaunchKernelGGL(gemm_kernel<P>, dim3(n_blocks), dim3(GEMM_THREADS * T::KG), T::LDS_BYTES, stream, p);
     ISDQN_HIP_CHECK(hipGetLastError());

@@ -1276,6 +1276,8 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const float* 
                                                           l.fwd_splits, slab_stride, st)
                 : plain_big<false, false, false, false, 2>(x3, A, nullptr, 0, B, slab, ldc, rows, l.out_f, l.in_f,
                                                            l.fwd_splits, slab_stride, st);
+    } else if (l.fwd_narrow) {  // few row tiles: 128 x 64 tiles reach the workgroup count with half the split-K slabs
+        rc = plain_narrow<false, false, 3>(x3, A, B, slab, ldc, rows, l.out_f, l.K, l.fwd_splits, slab_stride, st);
     } else {
         rc = plain_big<false, false, true, false, 3>(x3, A, nullptr, 0, B, slab, ldc, rows, l.out_f, l.K, l.fwd_splits, slab_stride,
                                                      st);  // activations and weights both S8
@@ -1752,6 +1754,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         auto launch_hc = [&](auto kern, int slot) -> int {
             static LdsConfigured configured[18];
             if (int rc2 = ensure_dynamic_lds(kern, lds, configured[slot])) return rc2;
+            ISDQN_REPORT_OCCUPANCY(kern, HC_THREADS, lds, hc_wg);
             hipLaunchKernelGGL(kern, dim3(hc_wg), dim3(HC_THREADS), lds, st, hp);
             ISDQN_HIP_CHECK(hipGetLastError());
             return ISDQN_OK;

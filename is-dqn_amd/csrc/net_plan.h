@@ -34,6 +34,7 @@ struct Layer {
     int64_t act_off, z_off, dz_off, gw_off, part_off;
     int gw_slabs;   // split-K slabs of the weight gradient
     int fwd_splits; // dense: split-K factor of the forward GEMM
+    bool fwd_narrow = false;  // dense forward on 128 x 64 tiles (S8 operands only)
     // conv: image-resident weight gradient (conv_img.h): 0 = use the generic engine
     int wgi_ntw, wgi_G, wgi_groups;
     // conv (layer >= 1): image-resident data gradient with the LayerNorm backward of the layer below fused in
@@ -247,9 +248,16 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
             if (s < 1) s = 1;
             l.gw_slabs = s;
             // forward split-K slabs
+            // ~512 workgroups (two per CU hide each other's operand latency).  A GEMM of few 128 x 128 tiles gets there with
+            // 128 x 64 tiles and half the split-K slabs: same time at the headline size, 32 MB less slab traffic per step.
             int ft = ceil_div(P.N2, 128) * ceil_div(l.out_p, 128);
-            int fs = ft >= 256 ? 1 : 512 / ft;  // ~512 workgroups: two per CU hide each other's operand latency
+            l.fwd_narrow = ft <= 64 && !l.in_unpadded_ld && l.out_p % 64 == 0;
+            if (l.fwd_narrow) ft = ceil_div(P.N2, 128) * ceil_div(l.out_p, 64);
+            int fs = ft >= 256 ? 1 : 512 / ft;
             int fk = ceil_div(l.K, 32);
+#if defined(ISDQN_DEV)
+            if (const char* e = getenv("ISDQN_FWD_SPLITS")) fs = atoi(e);  // development: split-K factor of the forward GEMM
+#endif
             if (fs > fk) fs = fk;
             if (fs < 1) fs = 1;
             l.fwd_splits = fs;

@@ -26,6 +26,9 @@ struct FrameSrc {
     int H, W;
     int id_pitch = 0, id_off = 0;  // unpaired: image j reads ids[j * id_pitch + id_off + c] (0: rows of `stack` ids) -- one half of a learn-layout table
     __device__ __forceinline__ int frame_id(int j, int c) const {
+#if defined(ISDQN_DEV)
+        if (ids == nullptr) return j * stack + c;  // (development experiment, conv_img.h)
+#endif
         if (paired_B > 0) {
             return j < paired_B ? ids[(int64_t)j * 2 * stack + c] : ids[(int64_t)(j - paired_B) * 2 * stack + stack + c];
         }
