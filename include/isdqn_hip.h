@@ -240,6 +240,17 @@ int isdqn_net_best_actions(const isdqn_net_config* cfg, const float* params, con
                            const int32_t* frame_ids, const float* obs, int32_t n_rows, const int32_t* idx_networks,
                            int32_t* out_actions, int32_t flags, void* workspace, void* stream);
 
+/* AnalysisNet.apply (slimdqn/utils/analysis_architecture.py:46-122) for the cnn / fc torsos with optional LayerNorm, as
+ * eval_srank_and_dead_neurons uses it (experiments/base/srank_and_dead_neurons.py:8-22): the network without its last layer on
+ * `n_rows` observations (<= 2 * batch_size).  features_out [n_rows][width of the last hidden layer] = its post-ReLU
+ * activations; scores_out = for every hidden layer in order, the sum over the rows of its post-ReLU activations in the
+ * reference's feature order ((H, W, C) flattened for conv layers) -- sizes from isdqn_net_analysis_layout.  The srank (an
+ * SVD) and the dead-neuron fraction are host arithmetic on these two arrays, as in the reference (utils/analysis.py:4-17). */
+int isdqn_net_analysis_layout(const isdqn_net_config* cfg, int32_t* n_hidden, int64_t* sizes, int32_t max_sizes);
+int isdqn_net_analysis(const isdqn_net_config* cfg, const float* params, const uint8_t* frames, int64_t frame_stride,
+                       const int32_t* frame_ids, const float* obs, int32_t n_rows, float* features_out, float* scores_out,
+                       void* workspace, void* stream);
+
 /* Engine self-test: C[M][N] = A . B on the MFMA tile engine for every operand-layout
  * combination (a_tr/b_tr: 0 = operand stored [rows][K], 1 = stored [K][rows]).  Test hook. */
 int isdqn_selftest_gemm(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t a_tr,

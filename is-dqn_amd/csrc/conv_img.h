@@ -212,6 +212,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
 #define ISDQN_ABLATED(bit) (false)
 #endif
     ISDQN_STAMP(0);
+    if (ISDQN_ABLATED(8)) return;  // (development: the cost of launching this grid with this LDS / register footprint)
     constexpr int mt0 = 0;
     int j, tile;
     xcd_image_tile((int)blockIdx.x, p.n_img, p.tiles_per_img, j, tile);

@@ -1047,6 +1047,46 @@ __global__ void argmax_kernel(const float* __restrict__ q, int A, int head, int*
     }
 }
 
+// AnalysisNet (slimdqn/utils/analysis_architecture.py:46-122): per-neuron sums over the rows of one hidden layer's post-ReLU
+// activations (S8 storage, [n_rows][pitch], `cpp` padded channels per pixel of which `c` are real), optionally also the
+// activations themselves as fp32 [n_rows][feat_ld] in the reference's (unpadded) feature order.  A workgroup owns 32 groups
+// of 8 elements; 8 row lanes stride over the rows and combine through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void act_rowsum_kernel(const float* __restrict__ act, int n_rows, int pitch, int cpp, int c,
+                                                         float* __restrict__ scores, float* __restrict__ feat, int feat_ld) {
+    __shared__ float s_sum[8][32][8];
+    const int gl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int e0 = ((int)blockIdx.x * 32 + gl) * 8;
+    const bool on = e0 < pitch;
+    const int pix = on ? e0 / cpp : 0, ch0 = on ? e0 % cpp : 0;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    if (on)
+        for (int r = rl; r < n_rows; r += 8) {
+            const float* src = act + (int64_t)r * pitch + e0;
+            const f32x4 h = *reinterpret_cast<const f32x4*>(src), l = *reinterpret_cast<const f32x4*>(src + 4);
+            const bf16x8 hi = __builtin_bit_cast(bf16x8, h), lo = __builtin_bit_cast(bf16x8, l);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = (float)hi[i] + (float)lo[i];
+                acc[i] += v;
+                if (feat != nullptr && ch0 + i < c) feat[(int64_t)r * feat_ld + pix * c + ch0 + i] = v;
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_sum[rl][gl][i] = acc[i];
+    __syncthreads();
+    if (rl == 0 && on) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += s_sum[k][gl][i];
+            if (ch0 + i < c) scores[pix * c + ch0 + i] = t;
+        }
+    }
+}
+
 // batched form: row i -> first argmax of head oh + idx[i] of its own q row
 __global__ __launch_bounds__(64) void argmax_rows_kernel(const float* __restrict__ q, int n_rows, int nha_p, int A, int oh, int K,
                                                          const int* __restrict__ idx, int* __restrict__ out) {
@@ -2173,6 +2213,53 @@ extern "C" int isdqn_net_best_actions(const isdqn_net_config* cfg, const float* 
     hipLaunchKernelGGL(argmax_rows_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, st, ws + P.q_off, n_rows, P.nha_p, P.n_actions,
                        P.oh, P.K, idx_networks, out_actions);
     ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
+// eval_srank_and_dead_neurons' device part (experiments/base/srank_and_dead_neurons.py:8-22): the torso on n_rows observations.
+extern "C" int isdqn_net_analysis_layout(const isdqn_net_config* cfg, int32_t* n_hidden, int64_t* sizes, int32_t max_sizes) {
+    int rc;
+    const Plan* Pp = cached_plan(cfg, &rc);
+    if (!Pp) return rc;
+    const Plan& P = *Pp;
+    ISDQN_REQUIRE(n_hidden != nullptr, ISDQN_ERR_ARG, "null pointer");
+    *n_hidden = P.n_layers - 1;
+    for (int i = 0; i < P.n_layers - 1 && sizes != nullptr && i < max_sizes; ++i) {
+        const Layer& l = P.L[i];
+        sizes[i] = l.kind == 0 ? (int64_t)l.npix * l.cout : (int64_t)l.out_f;
+    }
+    return ISDQN_OK;
+}
+
+extern "C" int isdqn_net_analysis(const isdqn_net_config* cfg, const float* params, const uint8_t* frames, int64_t frame_stride,
+                                  const int32_t* frame_ids, const float* obs, int32_t n_rows, float* features_out,
+                                  float* scores_out, void* workspace, void* stream) {
+    int rc;
+    const Plan* Pp = cached_plan(cfg, &rc);
+    if (!Pp) return rc;
+    const Plan& P = *Pp;
+    ISDQN_REQUIRE(params && features_out && scores_out && workspace, ISDQN_ERR_ARG, "null pointer");
+    ISDQN_REQUIRE(n_rows >= 1 && n_rows <= P.N2, ISDQN_ERR_SHAPE, "n_rows must be in [1, 2 * batch_size] (workspace rows)");
+    ISDQN_REQUIRE(P.n_layers >= 2, ISDQN_ERR_SHAPE, "no hidden layer");
+    rc = check_input(cfg, frames, frame_stride, frame_ids, obs);
+    if (rc) return rc;
+    NetInput in{frames, frame_stride, frame_ids, 0, obs, nullptr, 0};
+    float* ws = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    rc = refresh_mirror(P, params, ws, st);
+    if (rc) return rc;
+    rc = net_forward(P, cfg->precision == ISDQN_PRECISION_BF16X3, params, in, n_rows, 0, ws, ws + P.q_off, st, P.n_layers - 1);
+    if (rc) return rc;
+    int64_t off = 0;
+    for (int i = 0; i < P.n_layers - 1; ++i) {
+        const Layer& l = P.L[i];
+        const int cpp = l.kind == 0 ? l.cout_p : l.out_p, c = l.kind == 0 ? l.cout : l.out_f;
+        const bool last = i == P.n_layers - 2;
+        hipLaunchKernelGGL(act_rowsum_kernel, dim3(ceil_div(l.out_elems_p, 256)), dim3(256), 0, st, ws + l.act_off, n_rows, l.out_elems_p,
+                           cpp, c, scores_out + off, last ? features_out : nullptr, last ? (l.kind == 0 ? l.npix * l.cout : l.out_f) : 0);
+        ISDQN_HIP_CHECK(hipGetLastError());
+        off += l.kind == 0 ? (int64_t)l.npix * l.cout : (int64_t)l.out_f;
+    }
     return ISDQN_OK;
 }
 

@@ -39,11 +39,20 @@ def train(key, p: dict, agent, env, rb):
     vector = hasattr(env, "envs")  # VectorEnv: n environments per round, same per-step cadence of the updates
     run_return, run_length = ([0.0] * len(env), [0] * len(env)) if vector else (None, None)
 
+    analysis_logs = {"srank": [], "dead_neurons": []}
+
     def after_step():
         if n_training_steps > p["n_initial_samples"]:
             agent.update_online_params(n_training_steps, rb)
             updated, logs = agent.update_target_params(n_training_steps)
             if updated:
+                if p.get("analysis"):  # dqn.py:54-58 of the reference
+                    from experiments.base.srank_and_dead_neurons import eval_srank_and_dead_neurons
+
+                    at_update = eval_srank_and_dead_neurons(agent.params, rb, p)
+                    logs.update(at_update)
+                    for metric in analysis_logs:
+                        analysis_logs[metric].append(at_update[metric])
                 p["wandb"].log({"n_training_steps": n_training_steps, **logs})
 
     for idx_epoch in range(p["n_epochs"]):
@@ -90,7 +99,7 @@ def train(key, p: dict, agent, env, rb):
         if idx_epoch < p["n_epochs"] - 1:
             returns.append([0])
             lengths.append([0])
-        save_data(p, returns, lengths, model)
+        save_data(p, returns, lengths, model, analysis_logs)
         if os.environ.get("WORLD_SIZE", "1") != "1":  # rank 0: every replica's per-epoch metrics in one file
             replicas.write_gathered(os.path.join(os.path.dirname(os.path.dirname(p["save_path"])), "gathered_metrics.json"),
                                     gathered, EPOCH_FIELDS)

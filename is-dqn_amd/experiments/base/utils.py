@@ -100,3 +100,6 @@ def save_data(p: dict, episode_returns: list, episode_lengths: list, model, anal
     )
     if model is not None:
         pickle.dump(model, open(os.path.join(model_dir, str(p["seed"])), "wb"))
+    if p.get("analysis"):  # utils.py:137-144 of the reference: analysis/<seed>.json
+        os.makedirs(os.path.join(p["save_path"], "analysis"), exist_ok=True)
+        json.dump(analysis_logs, open(os.path.join(p["save_path"], "analysis", f"{p['seed']}.json"), "w"), indent=4)

@@ -320,6 +320,26 @@ class QNetEngine:
         self._mirror_holds(params)
         return self.action_out
 
+    def analysis(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, n_rows: int, params=None):
+        """AnalysisNet.apply (utils/analysis_architecture.py:46-122) on n_rows observations: (features [n_rows, width of the last
+        hidden layer], [per-layer sums over the rows of the post-ReLU activations, in the reference's shapes flattened])."""
+        n_hidden = ctypes.c_int32()
+        sizes = (ctypes.c_int64 * 8)()
+        _hip.check(self.lib.isdqn_net_analysis_layout(ctypes.byref(self.cfg), ctypes.byref(n_hidden), sizes, 8))
+        sizes = [int(sizes[i]) for i in range(n_hidden.value)]
+        feats = torch.empty(n_rows, sizes[-1], dtype=torch.float32, device=self.device)
+        scores = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
+        p = self.params if params is None else params
+        _hip.check(
+            self.lib.isdqn_net_analysis(
+                ctypes.byref(self.cfg), _hip.ptr(p), _hip.ptr(frames), int(frame_stride), _hip.ptr(frame_ids), _hip.ptr(obs),
+                int(n_rows), _hip.ptr(feats), _hip.ptr(scores), _hip.ptr(self.workspace), _hip.stream_ptr(self.device),
+            ),
+            "isdqn_net_analysis",
+        )
+        self._mirror_holds(params)
+        return feats, list(torch.split(scores, sizes))
+
     # ------------------------------------------------------------------ weight-mirror bookkeeping (acting path)
     # The library keeps a pre-split mirror of the weights in the workspace and rebuilds it at the head of every call unless
     # told that it is current.  learn_on_batch leaves it current; any torch-side in-place write to `self.params` bumps the

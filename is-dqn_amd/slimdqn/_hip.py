@@ -133,6 +133,11 @@ _SIGNATURES = {
         c_int32,
         [POINTER(NetConfig), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
     ),
+    "isdqn_net_analysis_layout": (c_int32, [POINTER(NetConfig), POINTER(c_int32), POINTER(c_int64), c_int32]),
+    "isdqn_net_analysis": (
+        c_int32,
+        [POINTER(NetConfig), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "isdqn_selftest_gemm": (
         c_int32,
         [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],

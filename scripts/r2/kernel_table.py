@@ -40,7 +40,7 @@ model = [
     (r"conv_fwd_img_kernel<2, 2, true", "conv0 fwd + LN + ReLU", 2 * B * 28224 + 2 * B * a0 * F4 + B * a0 * F4 + w0 * F4, 2 * 2 * B * 441 * 32 * 256, 2),
     (r"conv_fwd_img_kernel<4, 3, false, 2", "conv1 fwd + LN + ReLU", 2 * B * a0 * F4 + 2 * B * a1 * F4 + B * a1 * F4 + w1 * F4, 2 * 2 * B * 121 * 64 * 512, 3),
     (r"conv_fwd_img_kernel<4, 3, false, 1", "conv2 fwd + LN + ReLU", 2 * B * a1 * F4 + 2 * B * a2 * F4 + B * a2 * F4 + w2 * F4, 2 * 2 * B * 121 * 64 * 576, 3),
-    (r"PlainGemm<128, 128, 2, 2, false, false, 3, true, false, false", "dense0 fwd (split-K slabs)", 2 * B * a2 * F4 + wd * F4 + 2 * B * 512 * F4, 2 * 2 * B * 7744 * 512, 3),
+    (r"PlainGemm<128, (128|64), 2, 2, false, false, 3, true, false, false", "dense0 fwd (split-K slabs)", 2 * B * a2 * F4 + wd * F4 + 2 * B * 512 * F4, 2 * 2 * B * 7744 * 512, 3),
     (r"head_chain_kernel", "hidden LN + head GEMM + TD + head dgrad + LN bwd", 2 * B * 512 * F4 * 2 + wh * F4 + B * 512 * F4, 2 * 2 * B * 512 * NHA + 2 * B * K * 512, 3),
     (r"DenseDgradLN", "dense0 dgrad + LN/ReLU bwd of conv2", B * 512 * F4 + wd * F4 + B * a2 * F4 * 2, 2 * B * 7744 * 512, 3),
     (r"conv_dgrad_img_kernel<4, 3", "conv2 dgrad + LN/ReLU bwd of conv1", B * a2 * F4 + w2 * F4 + B * a1 * F4 * 2, 2 * B * 121 * 64 * 576, 3),
