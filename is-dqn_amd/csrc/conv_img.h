@@ -244,9 +244,9 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
         int c = tid + i * NTHR;
         a_on[i] = c < GA::CHUNKS;
         if (!a_on[i]) c = 0;
-        a_row[i] = c >> 2;
+        a_row[i] = stash_row(c);  // (lane quads take the rows of a block of four in the order 0, 2, 1, 3: gemm_core.h)
         a_var[i] = (c & 3) * 8;
-        a_lds[i] = (c >> 2) * GA::PITCH + (c & 3) * 8;
+        a_lds[i] = a_row[i] * GA::PITCH + (c & 3) * 8;
     }
     // Weight slices are fetched PF steps ahead into a ring of register sets: with one workgroup per CU nothing
     // else hides the L2 round trip, and one K step of MFMA work is shorter than it.
@@ -627,6 +627,7 @@ struct ConvWgradImgParams {
     int n_img, G;        // images per workgroup
     int n_col_groups, NC;  // k' columns per workgroup (multiple of 64)
     int R, Wp;           // input image: local rows (whole image), padded width
+    int PPin;            // fp32 layers: pixel pitch of the input image in elements (cin_p + pad, see conv_wgrad_img_kernel)
     int in_plane;        // elements of one precision plane of the input image
     int PA, npix_pad;    // dz image: row pitch (elements), rows padded to a multiple of 32
     int dz_plane;        // elements of one precision plane of the dz image
@@ -636,14 +637,14 @@ struct ConvWgradImgParams {
 
 template <bool U8, int PASSES, int NTHR = GEMM_THREADS>
 __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, const ConvGeom& g, const FrameSrc& fs,
-                                                 const float* in, int j, int row_base, int R, int Wp, int tid,
+                                                 const float* in, int j, int row_base, int R, int Wp, int PP, int tid,
                                                  const FastDiv& d_chunk, const FastDiv& d_Wp, const FastDiv& d_R) {
     constexpr int FILL_BATCH = 8;
     if constexpr (U8) {
         fill_frames_u8<NTHR>(img, fs, j, row_base, -g.pad, R, Wp, tid, d_chunk);
     } else {
         fill_image_s8<NTHR, (PASSES >= 3 ? 2 : 1), FILL_BATCH>(img, plane_elems, in + (int64_t)j * g.hin * g.win * g.cin_p, g.hin, g.win, g.cin_p,
-                                                               row_base, -g.pad, R, Wp, g.cin_p, tid, d_chunk, d_Wp);
+                                                               row_base, -g.pad, R, Wp, PP, tid, d_chunk, d_Wp);
     }
 }
 
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
             uint32_t tap, ci, ky, kx;
             g.d_cinp.divmod((uint32_t)(c0 < g.K ? c0 : 0), tap, ci);
             g.d_ksz.divmod(tap, ky, kx);
-            col_off[t] = ((int)ky * p.Wp + (int)kx) * g.cin_p + (int)ci + 4 * pq;
+            col_off[t] = ((int)ky * p.Wp + (int)kx) * p.PPin + (int)ci + 4 * pq;
         }
     }
 
@@ -702,21 +703,26 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
         // ---- dz image: [npix_pad][PA], rows >= npix are zero (one "row" of npix_pad pixels for the walker) ----
         fill_image_s8<NTHR, A_PLANES, 8>(dzi, p.dz_plane, p.dz + (int64_t)j * g.npix * g.cout_p, 1, g.npix, g.cout_p, 0, 0, 1, p.npix_pad,
                                          p.PA, tid, p.d_dzchunk, p.d_npixpad);
-        fill_input_image<U8, PASSES, NTHR>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, tid, p.d_chunk, p.d_Wp, p.d_R);
+        fill_input_image<U8, PASSES, NTHR>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, p.PPin, tid, p.d_chunk, p.d_Wp, p.d_R);
         __syncthreads();
 
         for (int ks = 0; ks < nsteps; ++ks) {
-            // the two 4-row blocks of this lane's 8-pixel group
+            // The two 4-row blocks of this lane's 8-pixel group.  The contraction order is free, so k row 8*grp + 4*h + q of
+            // the step takes pixel tr_row(.) of its 32: the eight k rows one 32-lane group of a ds_read_b64_tr_b16 addresses
+            // are then eight CONSECUTIVE pixels, which a pixel pitch of an odd multiple of 32 bytes (dz: PA; input: stride *
+            // PPin) spreads over all 64 banks.  In natural order the two k groups of a read sat 8 pixels apart on the same
+            // banks and the unpadded 128-byte input pixels made that 4-way (scripts/lds_conflicts.py; 60 % of the LDS cycles
+            // of these kernels were bank conflicts, profiles/round2).
             int pixoff[2], arow[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                int kp = ks * GEMM_BK + 8 * grp + 4 * h + q;
+                int kp = ks * GEMM_BK + tr_row(8 * grp + 4 * h + q);
                 arow[h] = kp * p.PA + 4 * pq;
                 kp = kp < g.npix ? kp : g.npix - 1;  // padded pixels: dz rows are zero, the input only has to be finite
                 uint32_t oy, ox;
                 g.d_wout.divmod((uint32_t)kp, oy, ox);
                 pixoff[h] = U8 ? ((int)oy * g.stride * p.Wp + (int)ox * g.stride)
-                               : ((int)oy * g.stride * p.Wp + (int)ox * g.stride) * g.cin_p;
+                               : ((int)oy * g.stride * p.Wp + (int)ox * g.stride) * p.PPin;
             }
             bf16x8 fa_hi[MT], fa_lo[MT];
 #pragma unroll
@@ -868,7 +874,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
         if (!a_on[i]) c = 0;
         const int kk = c / (BM / 8), rc = c % (BM / 8);
         a_ci0[i] = rc * 8; a_kk[i] = kk;
-        a_lds[i] = kk * GA::PITCH + rc * 8;
+        a_lds[i] = tr_row(kk) * GA::PITCH + rc * 8;
     }
     constexpr int PF = 4;  // weight slices in flight (register ring), as in conv_fwd_img_kernel
     float sa[PF][A_PER][8];

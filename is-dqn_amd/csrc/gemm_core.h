@@ -147,9 +147,26 @@ __device__ __forceinline__ void s8_store_elem(float* row, int c, float v) {
 }
 
 // LDS image geometry (in bf16 elements)
-template <int ROWS, bool TR>
+//   ROW images [rows][32 k]: pitch 48 elements = 96 bytes, (pitch / 16) = 2 (mod 4): the 16-lane groups of ds_read_b128 hit
+//     16 distinct bank quads (conv_img.h ConvImgTraits); the 80-byte pitch of round 1 gave 2-way conflicts on every read.
+//   TR images [32 k][rows]: a ds_read_b64_tr_b16 is served in two 32-lane groups; the lanes of one group address four k rows
+//     of two 8-row k groups, 8 bytes (2 banks) each at the same 4 column offsets.  With the k rows stored in natural order the
+//     two k groups sit 8 pitches apart and hit the same banks whatever the pitch (2-way, scripts/lds_conflicts.py).  The rows
+//     are therefore stored in the order tr_row() -- the eight rows one group reads become neighbours -- with a pitch of
+//     ROWS + 16 elements (an odd multiple of 32 bytes): conflict-free.  TR_PAD = 8 keeps round 1's pitch (still 2-way) for
+//     the one kernel whose four workgroups per CU would not fit otherwise.
+//   Stash writes (ds_write_b128: 8 contiguous lanes per LDS cycle, 32 four-byte banks): with the 96-byte pitch the chunks of
+//     rows r and r + 1 overlap in 8 banks, those of rows r and r + 2 do not -- stash_row() hands the lane quads of a ROW image
+//     the rows of every block of four in the order 0, 2, 1, 3 (row counts are multiples of 4).
+__device__ __forceinline__ constexpr int stash_row(int chunk) {  // row of 8-element chunk `chunk` (4 chunks per row)
+    return ((chunk >> 4) << 2) + (((chunk >> 2) & 1) << 1) + ((chunk >> 3) & 1);
+}
+__device__ __forceinline__ constexpr int tr_row(int kk) {  // LDS row of k row kk (kk < 32) of a TR image
+    return 16 * (kk >> 4) + 8 * ((kk >> 2) & 1) + 2 * (kk & 3) + ((kk >> 3) & 1);
+}
+template <int ROWS, bool TR, int TR_PAD = 16>
 struct TileGeom {
-    static constexpr int PITCH = TR ? (ROWS + 8) : (GEMM_BK + 8);
+    static constexpr int PITCH = TR ? (ROWS + TR_PAD) : (GEMM_BK + 16);
     static constexpr int ELEMS = TR ? GEMM_BK * PITCH : ROWS * PITCH;
     static constexpr int CHUNKS = ROWS * (GEMM_BK / 8);  // 8-element chunks per K step (same for both images)
     static constexpr int PER_THREAD = (CHUNKS + GEMM_THREADS - 1) / GEMM_THREADS;
@@ -176,8 +193,8 @@ __device__ __forceinline__ bf16x8 read_frag(const __bf16* tile, int row0, int la
         // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(rows) block; lane 4q+p supplies the address of
         // k-row q, rows 4p..4p+3; lane i receives row i of the 4 k-rows.
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-        const __bf16* a0 = tile + (8 * g + q) * PITCH + row0 + 4 * p;
-        const __bf16* a1 = a0 + 4 * PITCH;
+        const __bf16* a0 = tile + (16 * (g >> 1) + 2 * q + (g & 1)) * PITCH + row0 + 4 * p;  // tr_row(8 * g + q)
+        const __bf16* a1 = a0 + 8 * PITCH;                                                   // tr_row(8 * g + q + 4)
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)a0);
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)a1);
         s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -204,6 +221,15 @@ template <class P, class = void>
 struct KGroupsOf { static constexpr int value = 1; };
 template <class P>
 struct KGroupsOf<P, std::void_t<decltype(P::KG)>> { static constexpr int value = P::KG; };
+// TR-image pitch pads (problems that declare `static constexpr int TR_PAD_A / TR_PAD_B`; see TileGeom)
+template <class P, class = void>
+struct TrPadAOf { static constexpr int value = 16; };
+template <class P>
+struct TrPadAOf<P, std::void_t<decltype(P::TR_PAD_A)>> { static constexpr int value = P::TR_PAD_A; };
+template <class P, class = void>
+struct TrPadBOf { static constexpr int value = 16; };
+template <class P>
+struct TrPadBOf<P, std::void_t<decltype(P::TR_PAD_B)>> { static constexpr int value = P::TR_PAD_B; };
 // operands stored S8 (problems that declare `static constexpr bool A_S8 / B_S8`): staged by copy
 template <class P, class = void>
 struct AS8Of { static constexpr bool value = false; };
@@ -221,8 +247,8 @@ struct GemmTraits {
     static constexpr int PASSES = P::PASSES;
     static constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
     static constexpr int B_PLANES = PASSES >= 3 ? 2 : 1;
-    using GA = TileGeom<BM, P::A_TR>;
-    using GB = TileGeom<BN, P::B_TR>;
+    using GA = TileGeom<BM, P::A_TR, TrPadAOf<P>::value>;
+    using GB = TileGeom<BN, P::B_TR, TrPadBOf<P>::value>;
     static constexpr int STAGE_ELEMS = A_PLANES * GA::ELEMS + B_PLANES * GB::ELEMS;
     static constexpr int KG = KGroupsOf<P>::value;
     static constexpr int PIPE_BYTES = KG * 2 * STAGE_ELEMS * 2;
@@ -263,7 +289,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KGroupsOf<P>::value) void gemm_kerne
         a_on[i] = c < GA::CHUNKS;
         if (!a_on[i]) c = 0;
         if constexpr (!P::A_TR) {
-            int r = c >> 2, kc = c & 3;
+            int r = stash_row(c), kc = c & 3;
             actx[i] = p.a_ctx(tile, tile.m0 + r);
             a_var[i] = kc * 8;
             a_lds[i] = r * GA::PITCH + kc * 8;
@@ -271,7 +297,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KGroupsOf<P>::value) void gemm_kerne
             int kk = c / (T::BM / 8), rc = c % (T::BM / 8);
             actx[i] = p.a_ctx(tile, tile.m0 + rc * 8);
             a_var[i] = kk;
-            a_lds[i] = kk * GA::PITCH + rc * 8;
+            a_lds[i] = tr_row(kk) * GA::PITCH + rc * 8;
         }
     }
 #pragma unroll
@@ -280,7 +306,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KGroupsOf<P>::value) void gemm_kerne
         b_on[i] = c < GB::CHUNKS;
         if (!b_on[i]) c = 0;
         if constexpr (!P::B_TR) {
-            int r = c >> 2, kc = c & 3;
+            int r = stash_row(c), kc = c & 3;
             bctx[i] = p.b_ctx(tile, tile.n0 + r);
             b_var[i] = kc * 8;
             b_lds[i] = r * GB::PITCH + kc * 8;
@@ -288,7 +314,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KGroupsOf<P>::value) void gemm_kerne
             int kk = c / (T::BN / 8), rc = c % (T::BN / 8);
             bctx[i] = p.b_ctx(tile, tile.n0 + rc * 8);
             b_var[i] = kk;
-            b_lds[i] = kk * GB::PITCH + rc * 8;
+            b_lds[i] = tr_row(kk) * GB::PITCH + rc * 8;
         }
     }
 

@@ -1433,8 +1433,12 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
     conv_img_geometry(wp.g, l.is_u8, l.cin, 1, mt, 1, lds_unused_R, Wp, plane);
     wp.R = l.stride * (l.hout - 1) + l.ksz;  // the whole image
     wp.Wp = Wp;
-    wp.in_plane = l.is_u8 ? l.cin * wp.R * Wp : wp.R * Wp * l.cin_p;
-    wp.PA = l.cout_p + 8;
+    // pixel pitches: an odd multiple of 32 bytes between consecutive contraction pixels (dz rows: PA; input: stride * PPin)
+    wp.PPin = l.cin_p;
+    for (int pad = 0; pad <= 24; pad += 8)
+        if ((l.stride * (l.cin_p + pad)) % 32 == 16) { wp.PPin = l.cin_p + pad; break; }
+    wp.in_plane = l.is_u8 ? l.cin * wp.R * Wp : wp.R * Wp * wp.PPin;
+    wp.PA = l.cout_p + (l.cout_p % 32 == 0 ? 16 : 8);
     wp.npix_pad = round_up(l.npix, 32);
     wp.dz_plane = wp.npix_pad * wp.PA;
     const int lds = ((passes >= 2 ? 2 : 1) * wp.dz_plane + (passes >= 3 ? 2 : 1) * wp.in_plane) * 2;
@@ -1534,7 +1538,7 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
     dp.tiles_per_img = acc;
     const int mt = l.cin_p <= 32 ? 2 : 4;
     const int passes = x3 ? 3 : 1;
-    const int lds = (2 * (passes >= 2 ? 2 : 1) * 32 * (mt * 16 + 8) + (passes >= 3 ? 2 : 1) * dp.dz_plane) * 2;
+    const int lds = (2 * (passes >= 2 ? 2 : 1) * 32 * (mt * 16 + 16) + (passes >= 3 ? 2 : 1) * dp.dz_plane) * 2;  // TileGeom<.., true>
     if (lds > 150 * 1024) return ISDQN_OK;
     int rc;
     if (passes == 3) rc = mt == 2 ? launch_conv_dgrad_img<2, 3>(dp, st) : launch_conv_dgrad_img<4, 3>(dp, st);

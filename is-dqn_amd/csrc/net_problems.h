@@ -90,6 +90,8 @@ struct PlainGemm {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, PASSES = PASSES_;
     static constexpr bool A_TR = ATR, B_TR = BTR;
     static constexpr bool A_S8 = (S8M & 1) != 0, B_S8 = (S8M & 2) != 0;
+    // the fused-Adam GEMM lives off four workgroups per CU: only one of its two TR images gets the wider conflict-free pitch
+    static constexpr int TR_PAD_B = ADAM ? 8 : 16;
     MatSrc A, B;       // ROW: outer = rows, inner = K ; TR: outer = K, inner = rows
     const float* A2;   // optional second part of A (ROW only): rows >= a_split come from A2
     int a_split;
