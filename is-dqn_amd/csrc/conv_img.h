@@ -15,6 +15,42 @@
 
 namespace isdqn {
 
+// Which pixel a fragment column holds.  The B fragments of the image-resident kernels are ds_read_b128s at per-lane pixel
+// addresses; the hardware serves the columns {0-3, 12-15} of one k chunk together with the columns {4-11} of the next chunk
+// (MI355X_MICROARCH.md, LDS), and with a pixel pitch of (pitch / 16) = 2 (mod 4) each of the two sets is conflict-free exactly
+// when its 8 pixels are 8 consecutive positions of one image row.  So (a) column c of a 16-column tile holds position
+// column_slot(c) of the tile's 16 pixels -- the two sets become the tile's first and second 8 positions -- and (b) where the
+// whole image is resident the positions walk the pixel grid in 8-wide strips (row-major inside a strip), so that an aligned
+// run of 8 never wraps around a row.  Row-major 16-pixel tiles wrapped in every tile of an 11-pixel row: conflict factor 2.0
+// on these reads, 1.4 with this order (scripts/lds_conflicts.py; the epilogues are per pixel, any order serves them).
+__device__ __forceinline__ int column_slot(int c16) { return c16 < 4 ? 8 + c16 : (c16 < 12 ? c16 - 4 : c16); }
+struct PixelOrder {
+    int strips;   // 0: positions are row-major pixel indices
+    int n_full;   // positions inside the full 8-wide strips: H * 8 * (W / 8)
+    int full_w;   // 8 * (W / 8)
+    FastDiv d_h8, d_rem, d_w;  // by H * 8, by W % 8 (1 if none), by W
+    PixelOrder() : strips(0), n_full(0), full_w(0) {}
+    PixelOrder(int H, int W, bool use_strips) : strips(use_strips ? 1 : 0), n_full(H * 8 * (W / 8)), full_w(8 * (W / 8)) {
+        d_h8 = FastDiv((uint32_t)(H * 8));
+        d_rem = FastDiv((uint32_t)(W % 8 ? W % 8 : 1));
+        d_w = FastDiv((uint32_t)W);
+    }
+    // position n (< H * W) -> pixel (y, x)
+    __device__ __forceinline__ void map(int n, int& y, int& x) const {
+        uint32_t a, b;
+        if (!strips) {
+            d_w.divmod((uint32_t)n, a, b);
+            y = (int)a; x = (int)b;
+        } else if (n < n_full) {
+            d_h8.divmod((uint32_t)n, a, b);  // a: strip, b: position inside it
+            y = (int)(b >> 3); x = (int)(a * 8 + (b & 7));
+        } else {
+            d_rem.divmod((uint32_t)(n - n_full), a, b);
+            y = (int)a; x = full_w + (int)b;
+        }
+    }
+};
+
 struct ConvImgParams {
     ConvGeom g;
     MatSrc W;                // [cout_p][K], S8 mirror of the fp32 weights
@@ -31,6 +67,7 @@ struct ConvImgParams {
     int plane_elems;         // bf16 elements of one precision plane of the image
     int ablate;              // profiling only (env ISDQN_ABLATE): 1 skip fill, 2 skip K loop, 4 skip epilogue
     FastDiv d_chunk, d_Wp, d_R;  // fill index math: chunks per pixel (fp32) or per row (uint8), padded width, local rows
+    PixelOrder order;        // fp32 layers: which output pixel a fragment column holds (strips when the image is one tile)
     long long* stamps;       // profiling only (isdqn_debug_set_stamps): [workgroup][8] s_memtime / s_memrealtime at phase boundaries
 };
 
@@ -307,13 +344,21 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
     ISDQN_STAMP(1);  // fill loads consumed, LDS image written (this wave)
     // ---------------- per-lane patch origins of the two 16-pixel column tiles of this wave ----------------
     int b_org[NT];  // element offset of the patch origin inside one image plane
+    int out_pix[NT];  // output pixel of this lane's column (-1: past the image)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        int pp = p0 + wave * 32 + nt * 16 + (lane & 15);
-        pp = pp < g.npix ? pp : g.npix - 1;  // lanes past the image compute a duplicate pixel; never stored
-        uint32_t oy_u, ox_u;
-        g.d_wout.divmod((uint32_t)pp, oy_u, ox_u);
-        const int oy = (int)oy_u, ox = (int)ox_u;
+        int pp = p0 + wave * 32 + nt * 16 + (U8 ? (lane & 15) : column_slot(lane & 15));
+        const bool in_img = pp < g.npix;
+        pp = in_img ? pp : g.npix - 1;  // lanes past the image compute a duplicate pixel; never stored
+        int oy, ox;
+        if constexpr (U8) {
+            uint32_t oy_u, ox_u;
+            g.d_wout.divmod((uint32_t)pp, oy_u, ox_u);
+            oy = (int)oy_u; ox = (int)ox_u;
+        } else {
+            p.order.map(pp, oy, ox);
+        }
+        out_pix[nt] = in_img ? oy * g.wout + ox : -1;
         const int ly0 = oy * g.stride - g.pad - row_base;  // >= 0 by construction
         const int lx0 = ox * g.stride;                     // padded column of tap kx = 0
         b_org[nt] = U8 ? (ly0 * p.Wp + lx0) : (ly0 * p.Wp + lx0) * p.PP;
@@ -538,15 +583,14 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if (KG > 1 && nt != kg) continue;
-        const int pp = p0 + wave * 32 + nt * 16 + (lane & 15);
         float mean = 0.f, rstd = 1.f;
         if (p.gamma != nullptr) {
             mean = s1[nt] * inv_c;
             float var = fmaxf(s2[nt] * inv_c - mean * mean, 0.f);
             rstd = rsqrtf(var + 1e-6f);
         }
-        if (pp < g.npix) {
-            const int64_t pix = (int64_t)j * g.npix + pp;
+        if (out_pix[nt] >= 0) {
+            const int64_t pix = (int64_t)j * g.npix + out_pix[nt];
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 int ch0 = (mt0 + mt) * 16 + grp * 4;
@@ -806,7 +850,7 @@ struct ConvDgradImgParams {
     int dz_plane;
     int tiles_per_img;   // sum over classes of ceil(class pixels / 128)
     int cls_tile_start[5];
-    FastDiv cls_d_w[4];  // per class: divide by Wb (pixels per class row)
+    PixelOrder cls_order[4];  // per class: position inside the class -> (row, column) of the class grid (8-wide strips)
     int n_classes;
 };
 
@@ -930,12 +974,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     bool pix_ok[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        int q = q0 + wave * 32 + nt * 16 + (lane & 15);
+        int q = q0 + wave * 32 + nt * 16 + column_slot(lane & 15);
         pix_ok[nt] = q < n_cls_pix;
         q = pix_ok[nt] ? q : n_cls_pix - 1;
-        uint32_t a, b;
-        p.cls_d_w[cls].divmod((uint32_t)q, a, b);
-        const int iy = cy + g.stride * (int)a, ix = cx + g.stride * (int)b;
+        int a, b;
+        p.cls_order[cls].map(q, a, b);
+        const int iy = cy + g.stride * a, ix = cx + g.stride * b;
         pix_iy[nt] = iy; pix_ix[nt] = ix;
         const int oyb = (iy + g.pad - py) >> g.stride_sh, oxb = (ix + g.pad - px) >> g.stride_sh;  // (non-negative multiples of the stride)
         b_org[nt] = ((oyb + p.bt) * p.Wd + oxb + p.bt) * p.PPd;

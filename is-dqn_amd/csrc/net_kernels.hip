@@ -1190,9 +1190,25 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const floa
     // pixel pitch: +8 / +16 elements so that the 16 pixels of an MFMA column tile do not share LDS banks
     // (128-byte pixel rows put them 4-5 deep on the same banks; measured model in DESIGN.md)
     ip.PP = l.is_u8 ? 0 : l.cin_p + (l.cin_p % 64 == 0 ? 16 : 8);
-    const int lds = conv_img_geometry(ip.g, l.is_u8, l.cin, passes >= 3 ? 2 : 1, mt, passes >= 2 ? 2 : 1, ip.R, ip.Wp,
-                                      ip.plane_elems, ip.PP);
-    if (lds > 150 * 1024 || (l.is_u8 && (l.win < 8 || l.cin > 4))) return ISDQN_OK;  // (frame ids of a stack live in 4 registers)
+    int lds = conv_img_geometry(ip.g, l.is_u8, l.cin, passes >= 3 ? 2 : 1, mt, passes >= 2 ? 2 : 1, ip.R, ip.Wp,
+                                ip.plane_elems, ip.PP);
+    constexpr int LDS_LIMIT = 158 * 1024;  // of the 160 KB, minus the kernels' static arrays
+    if (lds > LDS_LIMIT || (l.is_u8 && (l.win < 8 || l.cin > 4))) return ISDQN_OK;  // (frame ids of a stack live in 4 registers)
+    // A row pitch of wout (mod 8) pixels keeps the bank pattern of a fragment's pixel columns going across the end of an
+    // image row (conv_img.h, PixelOrder: the short last strip of every row is where the conflicts are left); taken when it
+    // costs no workgroup per CU (11-pixel rows of the stride-2 layer: 24 -> 27 columns, conflict factor 1.75 -> 1.0).
+    if (!l.is_u8 && l.npix <= 128) {
+        const int want = ip.Wp + (((l.wout - ip.Wp) % 8) + 8) % 8;
+        const int planes = passes >= 3 ? 2 : 1;
+        const int lds2 = lds + planes * ip.R * (want - ip.Wp) * ip.PP * 2;
+        const int stage2 = (passes >= 2 ? 2 : 1) * (mt * 16) * 48 * 2 * 2;  // the second K group's stages (see kg2 below)
+        const int old_total = lds > 80 * 1024 ? lds + stage2 : lds, new_total = lds2 > 80 * 1024 ? lds2 + stage2 : lds2;
+        if (want != ip.Wp && new_total <= LDS_LIMIT && (old_total <= 80 * 1024) == (new_total <= 80 * 1024)) {
+            ip.Wp = want;
+            ip.plane_elems = ip.R * want * ip.PP;
+            lds = lds2;
+        }
+    }
     ip.W = MatSrc{wmir + l.w_off, l.K, l.cout_p, l.K, 1};
     ip.in = act_in;
     ip.fs = FrameSrc{in.frames, in.frame_stride, in.frame_ids, l.cin, in.paired_B, l.hin, l.win, in.id_pitch, in.id_off};
@@ -1205,6 +1221,7 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const floa
     ip.d_chunk = FastDiv((uint32_t)(l.is_u8 ? ip.Wp / 8 : l.cin_p / 8));
     ip.d_Wp = FastDiv((uint32_t)ip.Wp);
     ip.d_R = FastDiv((uint32_t)ip.R);
+    ip.order = PixelOrder(l.hout, l.wout, !l.is_u8 && ip.tiles_per_img == 1);
     ip.stamps = stamps_for(l.name);
     ip.ablate = 0;
 #if defined(ISDQN_DEV)
@@ -1219,7 +1236,7 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const floa
     // four waves, if the second pair of weight stages still fits and the accumulator exchange fits the image area.
     const int stage_bytes = (passes >= 2 ? 2 : 1) * (mt * 16) * 48 * 2 * 2;  // two stages of one K group
     static const bool no_kg = ISDQN_DEV_ENV("ISDQN_NO_KGROUPS");
-    const bool kg2 = !no_kg && mt == 4 && lds > 80 * 1024 && lds + stage_bytes <= 150 * 1024 &&
+    const bool kg2 = !no_kg && mt == 4 && lds > 80 * 1024 && lds + stage_bytes <= LDS_LIMIT &&
                      mt * 16 * 128 * 4 <= lds - stage_bytes && l.K >= 8 * GEMM_BK;
     if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false>(ip, st)
                           : kg2 ? launch_conv_fwd_img<4, 3, false, 2>(ip, st) : launch_conv_fwd_img<4, 3, false>(ip, st);
@@ -1531,7 +1548,7 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
         int cy = c / l.stride, cx = c % l.stride;
         int Ha = (l.hin - cy + l.stride - 1) / l.stride, Wb = (l.win - cx + l.stride - 1) / l.stride;
         dp.cls_tile_start[c] = acc;
-        dp.cls_d_w[c] = FastDiv((uint32_t)Wb);
+        dp.cls_order[c] = PixelOrder(Ha, Wb, Ha * Wb <= 128);  // (a class of several tiles keeps row-major tiles)
         acc += ceil_div(Ha * Wb, 128);
     }
     dp.cls_tile_start[dp.n_classes] = acc;
