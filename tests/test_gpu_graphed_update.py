@@ -86,3 +86,27 @@ def test_agent_update_online_params_graphed_equals_eager(prioritized):
     if prioritized:
         rb_g._sampling_distribution._sum_tree.check_status()
         assert rb_g._sampling_distribution._sum_tree.max_recorded_priority >= 1.0
+
+
+def test_priorities_ready_event_orders_a_second_stream():
+    """isdqn_batch.priorities_ready (include/isdqn_hip.h): the learn call records the caller's event once q_values / targets /
+    priorities are final.  A second stream that only waits for that event must read the same priorities as a full
+    synchronisation gives, while the call's own tail (backward, Adam) is still free to run."""
+    rep = _replica("c3")
+    eng, rb = rep.eng, rep.rb
+    batch = rb.sample()
+    ev = torch.cuda.Event()
+    side = torch.cuda.Stream()
+    ev.record(side)  # creates the handle
+    c = eng.make_batch(frames=batch.frames, frame_stride=batch.frame_stride, frame_ids=batch.frame_ids, action=batch.action,
+                       reward=batch.reward, terminal=batch.is_terminal, priorities_ready=ev)
+    eng.priorities.fill_(-1.0)
+    torch.cuda.synchronize()
+    eng.learn_on_batch(c)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        early = eng.priorities.clone()
+        q_early = eng.q_values.clone()
+    torch.cuda.synchronize()
+    assert torch.equal(early, eng.priorities) and torch.equal(q_early, eng.q_values)
+    assert bool((early >= 0).all()) and early.dtype == torch.float64
