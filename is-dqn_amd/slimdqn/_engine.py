@@ -354,12 +354,17 @@ class QNetEngine:
         """The call just enqueued rebuilt the mirror from `params` (None = the engine's own buffer)."""
         self._mirror_version = self.params._version if params is None else None
 
-    def best_actions(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, idx_networks: torch.Tensor, params=None) -> torch.Tensor:
-        """Greedy actions of n observations in one forward (isdqn.py:127-135 per row): int32 device tensor [n]."""
+    def best_actions(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, idx_networks: torch.Tensor, params=None,
+                     out: torch.Tensor | None = None, mirror_current: bool | None = None) -> torch.Tensor:
+        """Greedy actions of n observations in one forward (isdqn.py:127-135 per row): int32 device tensor [n].
+        ``mirror_current``: None = decided by the engine's bookkeeping; a captured graph fixes it at capture time."""
         n = int(idx_networks.numel())
-        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32, device=self.device)
         p = self.params if params is None else params
-        flags = _hip.BATCH_MIRROR_CURRENT if self._mirror_is_current(params) else 0
+        if mirror_current is None:
+            mirror_current = self._mirror_is_current(params)
+        flags = _hip.BATCH_MIRROR_CURRENT if mirror_current else 0
         _hip.check(
             self.lib.isdqn_net_best_actions(
                 ctypes.byref(self.cfg), _hip.ptr(p), _hip.ptr(frames), int(frame_stride), _hip.ptr(frame_ids), _hip.ptr(obs), n,
