@@ -241,3 +241,26 @@ def test_entry_point_with_vectorised_environments(tmp_path):
     res = json.load(open(tmp_path / "atari" / "exp_output" / "vec_Synthetic" / "isdqn" / "episode_returns_and_lengths" / "1.json"))
     assert len(res["episode_returns"]) == 2 and all(len(r) >= 1 for r in res["episode_returns"])
     assert all(l == 40 for epoch in res["episode_lengths"] for l in epoch)  # horizon-truncated episodes, whole ones only
+
+
+def test_fc_agent_acting_single_and_batched_match_oracle():
+    """BASELINE config 1's shape (LunarLander-style fc [100, 100], K = 1 is the DQN head count; here K = 2 heads + target): the
+    acting path of the fc architecture -- single observations (no frame ring) and batched rows -- against the oracle argmax."""
+    from oracle.isdqn import iSDQN as Oracle
+    from slimdqn.networks.isdqn import iSDQN
+    from tests.gpu_helpers import perturbed_params
+
+    K, A, B, feats, obs = 2, 4, 32, (100, 100), (8,)
+    params = perturbed_params(9, obs, feats, "fc", (1 + K) * A, True)
+    hip = iSDQN(0, obs, A, K, list(feats), True, False, "fc", 1e-3, 0.99, 1, 1, 4, adam_eps=1.5e-4, batch_size=B)
+    hip._engine.import_flax(params)
+    ora = Oracle(0, obs, A, K, list(feats), True, False, "fc", 1e-3, 0.99, 1, 1, 4, adam_eps=1.5e-4, params=params)
+    rng = np.random.default_rng(4)
+    states = rng.normal(size=(2 * B,) + obs).astype(np.float32)
+    heads = rng.integers(0, K, 2 * B)
+    got = hip.best_actions(hip.params, states, key=heads)
+    for i in range(2 * B):
+        want = ora.best_action(ora.params, states[i], int(heads[i]))
+        assert got[i] == want
+        if i < 6:
+            assert hip.best_action(hip.params, states[i], key=int(heads[i])) == want
