@@ -248,7 +248,7 @@ def main():
                     "timing sweep launch_job/atari/launch_time.sh:13-27 runs K in 1, 4, 9, 49)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--capacity", type=int, default=1_000_000)
-    ap.add_argument("--graph", type=int, default=8, help="most steps captured per hipGraph (0 = eager launches)")
+    ap.add_argument("--graph", type=int, default=32, help="most steps captured per hipGraph (0 = eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-capacity", type=int, default=1_000_000)
