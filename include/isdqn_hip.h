@@ -85,6 +85,30 @@ int isdqn_tree_query(const double* nodes, int32_t depth, const double* targets, 
  * the row gather below and, only for callers that want the reference's batch layout,
  * the stack materialisation. */
 
+/* ReplayBuffer.add, device side (replay_buffer.py:185-196: `self._memory[key] = ...`, the FIFO eviction and the sampler's
+ * index bookkeeping).  The host accumulator stages what changed since the last flush in one buffer -- byte offsets into
+ * `staged` below, every section 16-byte aligned -- and one launch scatters it:
+ *   frames[frame_slots[i]] <- frame_data[i]                          (n_frames new observations of frame_bytes bytes)
+ *   element row rows[r]    <- row_frames[r][stack2], row_action[r], row_reward[r], row_terminal[r]     (n_rows)
+ *   index_to_slot[index_rows[i]] <- index_vals[i]                                                      (n_index)   */
+typedef struct isdqn_staged_updates {
+    int32_t n_frames, frame_bytes;
+    int64_t off_frame_slots; /* int32 [n_frames]              */
+    int64_t off_frame_data;  /* uint8 [n_frames][frame_bytes] */
+    int32_t n_rows, stack2;
+    int64_t off_rows;         /* int32 [n_rows]               */
+    int64_t off_row_frames;   /* int32 [n_rows][stack2]       */
+    int64_t off_row_action;   /* int32 [n_rows]               */
+    int64_t off_row_reward;   /* float [n_rows]               */
+    int64_t off_row_terminal; /* uint8 [n_rows]               */
+    int32_t n_index, reserved;
+    int64_t off_index_rows;   /* int32 [n_index]              */
+    int64_t off_index_vals;   /* int32 [n_index]              */
+} isdqn_staged_updates;
+int isdqn_replay_apply_staged(const uint8_t* staged, const isdqn_staged_updates* updates, uint8_t* frames, int64_t frame_stride,
+                              int32_t* elem_frames, int32_t* elem_action, float* elem_reward, uint8_t* elem_terminal,
+                              int32_t* index_to_slot, void* stream);
+
 /* Gather the element rows of `B` sampled elements: frame ids [B][2*stack], action, reward,
  * terminal (itemgetter + np.stack of the scalar fields, replay_buffer.py:206-212).  `slots`
  * are element slots, or -- when `index_to_slot` is not NULL -- the sampler's dense indices

@@ -65,6 +65,60 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const uint8_t* __rest
 
 using namespace isdqn;
 
+// ReplayBuffer.add's device side (replay_buffer.py:185-196): everything the host accumulator changed since the last flush --
+// new frames, rewritten element rows, moved sampler indices -- arrives in ONE staged buffer and is scattered by one launch.
+// Workgroups [0, n_frames): one frame each (16-byte pieces); then the element rows; then the index -> slot pairs.
+__global__ __launch_bounds__(256) void apply_staged_kernel(const uint8_t* __restrict__ st, const isdqn_staged_updates u, int row_blocks,
+                                                           uint8_t* __restrict__ frames, int64_t frame_stride,
+                                                           int* __restrict__ elem_frames, int* __restrict__ elem_action,
+                                                           float* __restrict__ elem_reward, uint8_t* __restrict__ elem_terminal,
+                                                           int* __restrict__ index_to_slot) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (b < u.n_frames) {
+        const int slot = reinterpret_cast<const int*>(st + u.off_frame_slots)[b];
+        const uint8_t* src = st + u.off_frame_data + (int64_t)b * u.frame_bytes;
+        uint8_t* dst = frames + (int64_t)slot * frame_stride;
+        const int n16 = ((u.frame_bytes | (int)(frame_stride & 15)) & 15) == 0 ? u.frame_bytes / 16 : 0;
+        for (int i = t; i < n16; i += 256) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (int i = n16 * 16 + t; i < u.frame_bytes; i += 256) dst[i] = src[i];
+        return;
+    }
+    const int rb = b - u.n_frames;
+    if (rb < row_blocks) {
+        const int i = rb * 256 + t;
+        if (i < u.n_rows * u.stack2) {
+            const int r = i / u.stack2, c = i - r * u.stack2;
+            const int row = reinterpret_cast<const int*>(st + u.off_rows)[r];
+            elem_frames[(int64_t)row * u.stack2 + c] = reinterpret_cast<const int*>(st + u.off_row_frames)[i];
+            if (c == 0) {
+                elem_action[row] = reinterpret_cast<const int*>(st + u.off_row_action)[r];
+                elem_reward[row] = reinterpret_cast<const float*>(st + u.off_row_reward)[r];
+                elem_terminal[row] = (st + u.off_row_terminal)[r];
+            }
+        }
+        return;
+    }
+    const int i = (rb - row_blocks) * 256 + t;
+    if (i < u.n_index) index_to_slot[reinterpret_cast<const int*>(st + u.off_index_rows)[i]] = reinterpret_cast<const int*>(st + u.off_index_vals)[i];
+}
+
+extern "C" int isdqn_replay_apply_staged(const uint8_t* staged, const isdqn_staged_updates* u, uint8_t* frames, int64_t frame_stride,
+                                         int32_t* elem_frames, int32_t* elem_action, float* elem_reward, uint8_t* elem_terminal,
+                                         int32_t* index_to_slot, void* stream) {
+    ISDQN_REQUIRE(staged && u, ISDQN_ERR_ARG, "null pointer");
+    ISDQN_REQUIRE(u->n_frames >= 0 && u->n_rows >= 0 && u->n_index >= 0 && u->stack2 >= 1 && u->frame_bytes >= 0, ISDQN_ERR_ARG, "negative count");
+    ISDQN_REQUIRE(u->n_frames == 0 || frames, ISDQN_ERR_ARG, "null frame store");
+    ISDQN_REQUIRE(u->n_rows == 0 || (elem_frames && elem_action && elem_reward && elem_terminal), ISDQN_ERR_ARG, "null element table");
+    ISDQN_REQUIRE(u->n_index == 0 || index_to_slot, ISDQN_ERR_ARG, "null index table");
+    const int row_blocks = (u->n_rows * u->stack2 + 255) / 256, idx_blocks = (u->n_index + 255) / 256;
+    const int blocks = u->n_frames + row_blocks + idx_blocks;
+    if (blocks == 0) return ISDQN_OK;
+    hipLaunchKernelGGL(apply_staged_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, staged, *u, row_blocks, frames, frame_stride,
+                       elem_frames, elem_action, elem_reward, elem_terminal, index_to_slot);
+    ISDQN_HIP_CHECK(hipGetLastError());
+    return ISDQN_OK;
+}
+
 extern "C" int isdqn_replay_gather_rows(const int32_t* elem_frames, const int32_t* elem_action,
                                         const float* elem_reward, const uint8_t* elem_terminal, int32_t stack,
                                         const int32_t* index_to_slot, const int32_t* slots, int32_t B,

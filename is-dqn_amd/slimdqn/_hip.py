@@ -59,6 +59,15 @@ class TensorInfo(ctypes.Structure):
     ]
 
 
+class StagedUpdates(ctypes.Structure):  # isdqn_staged_updates
+    _fields_ = [
+        ("n_frames", c_int32), ("frame_bytes", c_int32), ("off_frame_slots", c_int64), ("off_frame_data", c_int64),
+        ("n_rows", c_int32), ("stack2", c_int32), ("off_rows", c_int64), ("off_row_frames", c_int64), ("off_row_action", c_int64),
+        ("off_row_reward", c_int64), ("off_row_terminal", c_int64),
+        ("n_index", c_int32), ("reserved", c_int32), ("off_index_rows", c_int64), ("off_index_vals", c_int64),
+    ]
+
+
 class Batch(ctypes.Structure):
     _fields_ = [
         ("B", c_int32),
@@ -82,6 +91,10 @@ _SIGNATURES = {
     "isdqn_tree_set": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "isdqn_tree_swap_remove": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "isdqn_tree_query": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "isdqn_replay_apply_staged": (
+        c_int32,
+        [c_void_p, POINTER(StagedUpdates), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "isdqn_replay_gather_rows": (
         c_int32,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
