@@ -127,9 +127,14 @@ struct PlainGemm {
     __device__ __forceinline__ void load_a(const Tile&, const ACtx& c, int var, float (&v)[8]) const {
         if constexpr (!ATR) {
             if constexpr (A2PART) {
+                // A.outer counts the rows of BOTH parts.  Each part bounds its own rows: tile rows past the last real
+                // row (a 128-row tile over 2B = 64 rows) would otherwise pass `row - a_split < A.outer` and read up to
+                // a_split rows beyond the end of the caller's second matrix -- results never stored, but a page fault
+                // when that matrix ends a mapped segment (round 2's intermittent abort in the fc learn step).
                 const bool second = c.fixed >= a_split;
                 MatSrc s = A;
                 s.base = second ? A2 : A.base;
+                s.outer = second ? A.outer - a_split : min(A.outer, a_split);
                 s.load<AL || A_S8>(second ? c.fixed - a_split : c.fixed, var, v);
             } else {
                 A.load<AL || A_S8>(c.fixed, var, v);

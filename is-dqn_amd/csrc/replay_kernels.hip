@@ -78,7 +78,12 @@ __global__ __launch_bounds__(256) void apply_staged_kernel(const uint8_t* __rest
         const int slot = reinterpret_cast<const int*>(st + u.off_frame_slots)[b];
         const uint8_t* src = st + u.off_frame_data + (int64_t)b * u.frame_bytes;
         uint8_t* dst = frames + (int64_t)slot * frame_stride;
-        const int n16 = ((u.frame_bytes | (int)(frame_stride & 15)) & 15) == 0 ? u.frame_bytes / 16 : 0;
+        // 16-byte pieces only when both sides are 16-byte aligned for EVERY frame: frame size and stride multiples of 16 and
+        // the bases of the staged frame block and of the frame store aligned (the host packer rounds its sections to 16 bytes,
+        // but this is a public entry point); otherwise bytes
+        const bool wide = ((u.frame_bytes | (int)(frame_stride & 15)) & 15) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(st + u.off_frame_data) | reinterpret_cast<uintptr_t>(frames)) & 15) == 0;
+        const int n16 = wide ? u.frame_bytes / 16 : 0;
         for (int i = t; i < n16; i += 256) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
         for (int i = n16 * 16 + t; i < u.frame_bytes; i += 256) dst[i] = src[i];
         return;
@@ -110,6 +115,15 @@ extern "C" int isdqn_replay_apply_staged(const uint8_t* staged, const isdqn_stag
     ISDQN_REQUIRE(u->n_frames == 0 || frames, ISDQN_ERR_ARG, "null frame store");
     ISDQN_REQUIRE(u->n_rows == 0 || (elem_frames && elem_action && elem_reward && elem_terminal), ISDQN_ERR_ARG, "null element table");
     ISDQN_REQUIRE(u->n_index == 0 || index_to_slot, ISDQN_ERR_ARG, "null index table");
+    // the int32 / float sections are read as such: 4-byte aligned offsets on a 4-byte aligned base
+    ISDQN_REQUIRE((reinterpret_cast<uintptr_t>(staged) & 3) == 0 &&
+                  ((u->off_frame_slots | u->off_rows | u->off_row_frames | u->off_row_action | u->off_row_reward | u->off_index_rows |
+                    u->off_index_vals) & 3) == 0,
+                  ISDQN_ERR_ARG, "staged int32/float sections must be 4-byte aligned");
+    ISDQN_REQUIRE(u->off_frame_slots >= 0 && u->off_frame_data >= 0 && u->off_rows >= 0 && u->off_row_frames >= 0 && u->off_row_action >= 0 &&
+                  u->off_row_reward >= 0 && u->off_row_terminal >= 0 && u->off_index_rows >= 0 && u->off_index_vals >= 0,
+                  ISDQN_ERR_ARG, "negative section offset");
+    ISDQN_REQUIRE(u->n_frames == 0 || frame_stride >= u->frame_bytes, ISDQN_ERR_SHAPE, "frame_stride < frame_bytes");
     const int row_blocks = (u->n_rows * u->stack2 + 255) / 256, idx_blocks = (u->n_index + 255) / 256;
     const int blocks = u->n_frames + row_blocks + idx_blocks;
     if (blocks == 0) return ISDQN_OK;

@@ -22,12 +22,18 @@ def rank_assignment(rank: int, games, first_seed: int, n_seeds: int):
     return games[rank % len(games)], first_seed + (rank // len(games)) % n_seeds
 
 
-def init_from_env(backend: str = None):
+def init_from_env(backend: str = None, force: bool = False):
     """Join the job the launcher (experiments/launch.py or torchrun) described in the environment.  Selects this rank's
-    GPU before anything touches it; returns (world_size, rank).  A single-process run is a no-op."""
+    GPU before anything touches it; returns (world_size, rank).  A single-process run is a no-op unless `force` (or
+    ISDQN_DIST_FORCE=1) asks for a one-rank process group: that runs every line of the RCCL branch -- communicator set-up,
+    all_gather, all_reduce, barrier -- on a single GPU (the smoke test of the N > 1 path that needs no multi-GPU node)."""
     ws, rank, local_rank = world()
-    if ws <= 1:
+    force = force or os.environ.get("ISDQN_DIST_FORCE") == "1"
+    if ws <= 1 and not force:
         return 1, 0
+    if ws <= 1:
+        ws, rank = 1, 0
+        os.environ.setdefault("MASTER_PORT", "29531")
     import torch
     import torch.distributed as dist
 
