@@ -14,10 +14,9 @@ if _PKG not in sys.path:
 import numpy as np
 
 from experiments.base.dqn import train
+from experiments.atari.common import make_environment, make_replay, seeds
 from experiments.base.utils import prepare_logs
 from slimdqn.networks.isdqn import iSDQN
-from slimdqn.sample_collection.replay_buffer import ReplayBuffer
-from slimdqn.sample_collection.samplers import PrioritizedSamplingDistribution, UniformSamplingDistribution
 
 
 def run(argvs=sys.argv[1:], root=None):
@@ -25,38 +24,9 @@ def run(argvs=sys.argv[1:], root=None):
 
     replicas.init_from_env()  # one process per GPU: picks this rank's device before the first GPU call (no-op alone)
     p = prepare_logs("atari", "isdqn", argvs, root=root)
-    rng = np.random.default_rng(p["seed"])
-    q_seed, train_seed = (int(s) for s in rng.integers(0, 2**31 - 1, size=2))
-
-    game = p["experiment_name"].split("_")[-1]
-    if p["env_backend"] == "synthetic":
-        from slimdqn.environments.synthetic import SyntheticAtariEnv
-
-        make_env = lambda i: SyntheticAtariEnv(game, seed=p["seed"] + 1000 * i)
-    else:
-        from slimdqn.environments.atari import AtariEnv
-
-        make_env = lambda i: AtariEnv(game)
-    if p["n_envs"] > 1:  # not in the reference: n host environments acted on with one batched forward per round
-        from slimdqn.environments.vector import VectorEnv
-
-        env = VectorEnv([make_env(i) for i in range(p["n_envs"])])
-    else:
-        env = make_env(0)
-    if p["prioritized"]:
-        sampler = PrioritizedSamplingDistribution(p["seed"], p["replay_buffer_capacity"])
-    else:
-        sampler = UniformSamplingDistribution(p["seed"])
-    rb = ReplayBuffer(
-        sampling_distribution=sampler,
-        max_capacity=p["replay_buffer_capacity"],
-        batch_size=p["batch_size"],
-        update_horizon=p["update_horizon"],
-        gamma=p["gamma"],
-        clipping=lambda x: np.clip(x, -1, 1),
-        stack_size=4,
-        compress=True,
-    )
+    q_seed, train_seed = seeds(p)
+    env = make_environment(p)  # (worker processes of a VectorEnv start here, before this process's first GPU call)
+    rb = make_replay(p, prioritized=p["prioritized"])
     agent = iSDQN(
         q_seed,
         (env.state_height, env.state_width, env.n_stacked_frames),
@@ -78,7 +48,11 @@ def run(argvs=sys.argv[1:], root=None):
     )
     if p["prioritized"]:
         _wire_prioritized(agent, rb)
-    out = train(np.random.default_rng(train_seed), p, agent, env, rb)
+    try:
+        out = train(np.random.default_rng(train_seed), p, agent, env, rb)
+    finally:
+        if hasattr(env, "close"):
+            env.close()
     replicas.finalize()
     return out
 

@@ -41,19 +41,39 @@ def train(key, p: dict, agent, env, rb):
 
     analysis_logs = {"srank": [], "dead_neurons": []}
 
+    def after_target_update(step, logs):
+        if p.get("analysis"):  # dqn.py:54-58 of the reference
+            from experiments.base.srank_and_dead_neurons import eval_srank_and_dead_neurons
+
+            at_update = eval_srank_and_dead_neurons(agent.params, rb, p)
+            logs.update(at_update)
+            for metric in analysis_logs:
+                analysis_logs[metric].append(at_update[metric])
+        p["wandb"].log({"n_training_steps": step, **logs})
+
     def after_step():
         if n_training_steps > p["n_initial_samples"]:
             agent.update_online_params(n_training_steps, rb)
             updated, logs = agent.update_target_params(n_training_steps)
             if updated:
-                if p.get("analysis"):  # dqn.py:54-58 of the reference
-                    from experiments.base.srank_and_dead_neurons import eval_srank_and_dead_neurons
+                after_target_update(n_training_steps, logs)
 
-                    at_update = eval_srank_and_dead_neurons(agent.params, rb, p)
-                    logs.update(at_update)
-                    for metric in analysis_logs:
-                        analysis_logs[metric].append(at_update[metric])
-                p["wandb"].log({"n_training_steps": n_training_steps, **logs})
+    def after_round(first_step, count):
+        """The cadence of `after_step` for the steps first_step+1 .. first_step+count of one vector round, with the gradient
+        steps between two target updates issued together (agent.learn_steps: one graph replay)."""
+        owed = 0
+        for step in range(first_step + 1, first_step + count + 1):
+            if step <= p["n_initial_samples"]:
+                continue
+            if step % agent.data_to_update == 0:
+                owed += 1
+            if step % agent.target_update_frequency == 0:
+                agent.learn_steps(owed, rb)
+                owed = 0
+                updated, logs = agent.update_target_params(step)
+                if updated:
+                    after_target_update(step, logs)
+        agent.learn_steps(owed, rb)
 
     for idx_epoch in range(p["n_epochs"]):
         steps_in_epoch, has_reset = 0, False
@@ -62,9 +82,10 @@ def train(key, p: dict, agent, env, rb):
             returns[idx_epoch], lengths[idx_epoch] = [], []  # finished episodes of this epoch, any environment
         while steps_in_epoch < p["n_training_steps_per_epoch"] or not has_reset:
             if vector:
-                for i, (reward, ended) in enumerate(collect_vector_samples(rng, env, agent, rb, p, epsilon_schedule, n_training_steps)):
-                    steps_in_epoch += 1
-                    n_training_steps += 1
+                # (collects the round started by the previous call, starts the next one, returns: the gradient steps below
+                # are enqueued while the emulators run)
+                round_results = collect_vector_samples(rng, env, agent, rb, p, epsilon_schedule, n_training_steps)
+                for i, (reward, ended) in enumerate(round_results):
                     run_return[i] += reward
                     run_length[i] += 1
                     if ended:
@@ -72,7 +93,9 @@ def train(key, p: dict, agent, env, rb):
                         lengths[idx_epoch].append(run_length[i])
                         run_return[i], run_length[i] = 0.0, 0
                         has_reset = True
-                    after_step()
+                after_round(n_training_steps, len(round_results))
+                steps_in_epoch += len(round_results)
+                n_training_steps += len(round_results)
                 continue
             reward, has_reset = collect_single_sample(rng, env, agent, rb, p, epsilon_schedule, n_training_steps)
             steps_in_epoch += 1

@@ -42,6 +42,7 @@ _ENGINE = [
     ("-per", "--prioritized", dict(action="store_true", default=False, help="Prioritized replay (sum-tree on the GPU) with TD-error writeback.")),
     ("-hd", "--huber_delta", dict(type=float, default=0.0, help="0: squared TD error (the reference's loss); > 0: Huber loss with this delta.")),
     ("-nenvs", "--n_envs", dict(type=int, default=1, help="Host environments stepped in lockstep with one batched best_actions forward (1 = the reference's loop).")),
+    ("-nworkers", "--n_env_workers", dict(type=int, default=0, help="Host worker processes stepping the -nenvs environments in parallel (0 = in this process).")),
     ("-env", "--env_backend", dict(type=str, default="ale", choices=["ale", "synthetic"], help="'synthetic' replaces ALE by random frames (no ROMs needed).")),
 ]
 

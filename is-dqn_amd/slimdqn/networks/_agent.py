@@ -249,6 +249,42 @@ class EngineAgent:
         out = eng.best_actions(idx_networks=idx, params=self._bind(params), **self._states_to_device(states))
         return out.cpu().numpy()
 
+    def _best_actions_planes(self, params, planes: np.ndarray, rows: np.ndarray, idx_networks) -> np.ndarray:
+        """Greedy actions of the environments ``rows`` of a VectorEnv: ``planes`` is its host block uint8 [n][stack][h*w]
+        (planar stacks, oldest .. newest; pinned when the runtime registered the mapping).  ONE host-to-device copy of the
+        block, one small copy of (plane ids, head indices), one forward over len(rows) observations, one read-back."""
+        eng = self._engine
+        n, stack, hw = planes.shape
+        v = getattr(self, "_vec", None)
+        if v is None or v["dev"].shape != (n * stack, hw) or v["dev"].device != eng.device:
+            v = self._vec = dict(
+                dev=torch.empty(n * stack, hw, dtype=torch.uint8, device=eng.device),
+                small=torch.empty(n * (stack + 1), dtype=torch.int32, device=eng.device),
+                host_small=torch.empty(n * (stack + 1), dtype=torch.int32).pin_memory(),
+                out=torch.empty(n, dtype=torch.int32, device=eng.device),
+                host_out=torch.empty(n, dtype=torch.int32).pin_memory(),
+                ar=np.arange(stack, dtype=np.int32),
+            )
+        m = len(rows)
+        v["dev"].copy_(torch.from_numpy(planes.reshape(n * stack, hw)), non_blocking=True)
+        hs = v["host_small"].numpy()
+        hs[: m * stack] = (np.asarray(rows, np.int32)[:, None] * stack + v["ar"][None, :]).reshape(-1)
+        hs[n * stack : n * stack + m] = np.asarray(idx_networks, np.int32)
+        v["small"].copy_(v["host_small"], non_blocking=True)
+        eng.best_actions(frames=v["dev"], frame_stride=hw, frame_ids=v["small"][: m * stack], idx_networks=v["small"][n * stack : n * stack + m],
+                         params=self._bind(params), out=v["out"][:m])
+        v["host_out"][:m].copy_(v["out"][:m], non_blocking=True)
+        torch.cuda.current_stream(eng.device).synchronize()
+        return v["host_out"][:m].numpy().astype(np.int64)
+
+    # generic forms (one head, per-step replays); iSDQN overrides both
+    def best_actions_planes(self, params, planes, rows, key=None) -> np.ndarray:
+        return self._best_actions_planes(params, planes, rows, np.zeros(len(rows), dtype=np.int32))
+
+    def learn_steps(self, n_steps: int, replay_buffer) -> None:
+        for _ in range(n_steps):
+            self.update_online_params(0, replay_buffer)
+
     def _q_row(self, params, state) -> torch.Tensor:
         """network.apply on one observation: device row of n_heads * n_actions values."""
         return self._engine.forward(n_rows=1, params=self._bind(params), **self._obs_to_device(state))

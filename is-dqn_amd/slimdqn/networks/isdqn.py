@@ -82,6 +82,32 @@ class iSDQN(EngineAgent):
             g = self._graphed = GraphedUpdate(replay_buffer, eng, prioritized, steps_per_graph=1, writeback=self.priority_writeback)
         return g
 
+    def learn_steps(self, n_steps: int, replay_buffer) -> None:
+        """``n_steps`` consecutive gradient steps (sample -> learn -> [write-back] each) on an unchanged replay buffer: what
+        n_steps calls of ``update_online_params`` at update steps do, as ONE graph replay when the replay is this GPU's
+        device replay (a round of vectorised environments owes several steps at once; per-step replays cost the host
+        ~280 us each -- about what the GPU needs for the step)."""
+        if n_steps <= 0:
+            return
+        g1 = self._graphed_update(replay_buffer)
+        if g1 is None or n_steps == 1:
+            for _ in range(n_steps):
+                self.update_online_params(0, replay_buffer)
+            return
+        many = getattr(self, "_graphed_many", None)
+        if many is None or many[0] is not g1:
+            many = self._graphed_many = (g1, {})
+        g = many[1].get(n_steps)
+        if g is None:
+            if len(many[1]) >= 4:  # (rounds owe a constant number of steps; a changing one takes single-step replays)
+                for _ in range(n_steps):
+                    g1.run()
+                return
+            from slimdqn._graph import GraphedUpdate
+
+            g = many[1][n_steps] = GraphedUpdate(g1.rb, g1.eng, g1.prioritized, steps_per_graph=n_steps, writeback=g1.writeback)
+        g.run()
+
     def update_online_params(self, step: int, replay_buffer):
         if step % self.data_to_update == 0:
             g = self._graphed_update(replay_buffer)
@@ -151,6 +177,17 @@ class iSDQN(EngineAgent):
         else:
             idx = int(key.integers(0, self.n_bellman_iterations))
         return self._best_action(params, state, idx)
+
+    def best_actions_planes(self, params, planes, rows, key=None) -> np.ndarray:
+        """``best_actions`` on the planar host block of a VectorEnv (environments/vector.py) for its environments ``rows``."""
+        n = len(rows)
+        if key is None:
+            idx = self._action_rng.integers(0, self.n_bellman_iterations, size=n)
+        elif isinstance(key, np.random.Generator):
+            idx = key.integers(0, self.n_bellman_iterations, size=n)
+        else:
+            idx = np.broadcast_to(np.asarray(key), (n,))
+        return self._best_actions_planes(params, planes, rows, idx)
 
     def best_actions(self, params, states, key=None) -> np.ndarray:
         """``best_action`` for n observations (vectorised host environments): one head draw per observation from ``key``

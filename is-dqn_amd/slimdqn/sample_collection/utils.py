@@ -46,36 +46,43 @@ def collect_single_sample(key, env, agent, rb: ReplayBuffer, p, epsilon_schedule
 
 
 def collect_vector_samples(key, venv, agent, rb: ReplayBuffer, p, epsilon_schedule, n_training_steps: int):
-    """One round of ``collect_single_sample`` over the n environments of a VectorEnv: the epsilon draws per environment as in
-    ``select_action``, ONE batched forward for the greedy ones, then every environment steps and adds to its own stream
-    of the replay buffer.  Returns [(reward, episode_end)] in environment order."""
+    """One round of ``collect_single_sample`` (utils.py:21-43) over the n environments of a VectorEnv, pipelined:
+
+      1. the environment steps started by the PREVIOUS call are collected (``step_wait``) and their n transitions enter the
+         replay buffer, each on its own n-step accumulator (``stream=i``);
+      2. the next actions are chosen from the environments' current frame stacks -- epsilon draws per environment as in
+         ``select_action`` (environment i of the round uses the schedule at step n_training_steps + results + i, which is what
+         n consecutive ``collect_single_sample`` calls would use), ONE batched forward and one read-back for the greedy ones;
+      3. ``step_async`` starts the next round and the call returns, so the caller enqueues the round's gradient steps while the
+         emulators run (with worker processes: in parallel on the host cores, under the update kernels).
+
+    Returns [(reward, episode_end)] of the collected round in environment order -- empty on the very first call.
+    Image observations only (the stacks travel as uint8 planes); an fc agent keeps ``collect_single_sample``."""
+    assert getattr(agent, "architecture_type", "cnn") != "fc", "vectorised acting moves uint8 frame stacks: fc observations would be truncated"
     n = len(venv)
-    actions = np.empty(n, dtype=np.int64)
-    greedy = []
-    for i in range(n):
-        if key.random() <= epsilon_schedule(n_training_steps + i):
-            actions[i] = key.integers(0, venv.n_actions)
-        else:
-            greedy.append(i)
-    if greedy:
-        states = np.stack([np.asarray(venv.envs[i].state).astype(np.uint8, copy=False) for i in greedy])
-        actions[greedy] = agent.best_actions(agent.params, states, key=key)
     out = []
-    for i, env in enumerate(venv.envs):
-        obs = env.observation
-        reward, absorbing = env.step(int(actions[i]))
-        episode_end = absorbing or env.n_steps >= p["horizon"]
-        rb.add(
-            TransitionElement(
-                observation=obs,
-                action=int(actions[i]),
-                reward=reward if rb._clipping is None else rb._clipping(reward),
-                is_terminal=absorbing,
-                episode_end=episode_end,
-            ),
-            stream=i,
-        )
-        if episode_end:
-            env.reset()
-        out.append((reward, episode_end))
+    if not getattr(venv, "_pin_tried", False):  # the planar block goes up once per round: from pinned memory where the runtime allows
+        venv._pin_tried = True
+        venv.pin()
+    if venv._pending:
+        obs, reward, absorbing, episode_end = venv.step_wait()
+        actions = venv._last_actions
+        clip = rb._clipping
+        for i in range(n):
+            r = float(reward[i])
+            rb.add(TransitionElement(observation=obs[i], action=int(actions[i]), reward=r if clip is None else clip(r),
+                                     is_terminal=bool(absorbing[i]), episode_end=bool(episode_end[i])), stream=i)
+            out.append((r, bool(episode_end[i])))
+    first = n_training_steps + len(out)
+    eps = np.fromiter((epsilon_schedule(first + i) for i in range(n)), dtype=np.float64, count=n)
+    explore = key.random(n) <= eps
+    actions = np.empty(n, dtype=np.int64)
+    n_explore = int(explore.sum())
+    if n_explore:
+        actions[explore] = key.integers(0, venv.n_actions, size=n_explore)
+    if n_explore < n:
+        greedy = np.flatnonzero(~explore)
+        actions[greedy] = agent.best_actions_planes(agent.params, venv.planes, greedy, key=key)
+    venv._last_actions = actions
+    venv.step_async(actions)
     return out

@@ -184,7 +184,8 @@ def test_batched_best_actions_match_single_and_oracle():
 
 
 def test_vector_collection_round():
-    """collect_vector_samples: one batched forward for the greedy environments, every transition into its own stream."""
+    """collect_vector_samples: pipelined rounds (collect the previous round, act, start the next), one batched forward for the
+    greedy environments read from the planar host block, every transition into its own n-step stream."""
     from slimdqn.environments.synthetic import SyntheticAtariEnv
     from slimdqn.environments.vector import VectorEnv
     from slimdqn.sample_collection.replay_buffer import ReplayBuffer
@@ -192,16 +193,24 @@ def test_vector_collection_round():
     from slimdqn.sample_collection.utils import collect_vector_samples
 
     K, A, B = 3, 5, 8
-    hip, _ = _agents(K, A, B)
-    venv = VectorEnv([SyntheticAtariEnv("Synthetic", n_actions=A, seed=10 + i, episode_length=7 + i) for i in range(4)])
+    hip, ora = _agents(K, A, B)
+    venv = VectorEnv([SyntheticAtariEnv("Synthetic", n_actions=A, seed=10 + i, episode_length=7 + i) for i in range(4)], horizon=1000)
     venv.reset()
     assert venv.states.shape == (4, 84, 84, 4) and venv.states.dtype == np.uint8
+    # acting from the planar block == acting from (n, h, w, stack) states == the oracle's argmax
+    heads = np.array([0, 2, 1], np.int32)
+    rows = np.array([3, 0, 2])
+    got = hip.best_actions_planes(hip.params, venv.planes, rows, key=heads)
+    np.testing.assert_array_equal(got, hip.best_actions(hip.params, venv.states[rows], key=heads))
+    for r, h, a in zip(rows, heads, got):
+        assert a == ora.best_action(ora.params, venv.states[r], int(h))
     rb = ReplayBuffer(UniformSamplingDistribution(3), B, 500, update_horizon=3, gamma=0.99)
     rng = np.random.default_rng(0)
-    ends = 0
-    for t in range(30):
-        out = collect_vector_samples(rng, venv, hip, rb, {"horizon": 1000}, lambda step: 0.3, 4 * t)
-        assert len(out) == 4
+    ends, n_steps = 0, 0
+    for t in range(31):
+        out = collect_vector_samples(rng, venv, hip, rb, {"horizon": 1000}, lambda step: 0.3, n_steps)
+        assert len(out) == (0 if t == 0 else 4)  # the first call only starts a round
+        n_steps += len(out)
         ends += sum(e for _, e in out)
     assert ends >= 8 and len(rb._trajectories) == 4
     assert rb.add_count > 80
@@ -241,6 +250,20 @@ def test_entry_point_with_vectorised_environments(tmp_path):
     res = json.load(open(tmp_path / "atari" / "exp_output" / "vec_Synthetic" / "isdqn" / "episode_returns_and_lengths" / "1.json"))
     assert len(res["episode_returns"]) == 2 and all(len(r) >= 1 for r in res["episode_returns"])
     assert all(l == 40 for epoch in res["episode_lengths"] for l in epoch)  # horizon-truncated episodes, whole ones only
+
+
+def test_entry_point_with_environment_worker_processes(tmp_path):
+    """-nenvs 8 -nworkers 2: the emulators on host worker processes, gradient steps of a round issued as one graph replay."""
+    from experiments.atari.isdqn import run
+
+    argv = ["-en", "work_Synthetic", "-s", "2", "-dw", "-f", "8", "8", "8", "16", "-rbc", "400", "-bs", "8", "-n", "1", "-horizon", "25",
+            "-at", "cnn", "-ne", "2", "-ntspe", "160", "-utd", "4", "-nis", "40", "-ed", "100", "-nbi", "2", "-ln", "-tuf", "64",
+            "-env", "synthetic", "-nenvs", "8", "-nworkers", "2"]
+    gathered = run(argv, root=str(tmp_path))
+    assert len(gathered) == 2 and gathered[0].shape == (1, 4)
+    res = json.load(open(tmp_path / "atari" / "exp_output" / "work_Synthetic" / "isdqn" / "episode_returns_and_lengths" / "2.json"))
+    assert len(res["episode_returns"]) == 2 and all(len(r) >= 8 for r in res["episode_returns"])
+    assert all(l == 25 for epoch in res["episode_lengths"] for l in epoch)
 
 
 def test_fc_agent_acting_single_and_batched_match_oracle():
