@@ -245,7 +245,7 @@ class EngineAgent:
     def _best_actions(self, params, states, idx_networks) -> np.ndarray:
         """Greedy actions of n observations in one forward and one device->host copy."""
         eng = self._engine
-        idx = torch.as_tensor(np.asarray(idx_networks, dtype=np.int32)).to(eng.device)
+        idx = torch.as_tensor(np.array(idx_networks, dtype=np.int32)).to(eng.device)
         out = eng.best_actions(idx_networks=idx, params=self._bind(params), **self._states_to_device(states))
         return out.cpu().numpy()
 
