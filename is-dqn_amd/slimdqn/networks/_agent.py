@@ -107,6 +107,10 @@ class EngineAgent:
 
     # ------------------------------------------------------------------ batches
     def _c_batch(self, eng: QNetEngine, samples):
+        if hasattr(samples, "frame_ids") and self.architecture_type == "fc":
+            # device replay of vector observations (LunarLander): the stored float32 bytes come back as (B, d) rows
+            return eng.make_batch(state=samples.state, next_state=samples.next_state, action=samples.action, reward=samples.reward,
+                                  terminal=samples.is_terminal)
         if hasattr(samples, "frame_ids"):  # DeviceBatch from the device replay
             return eng.make_batch(
                 frames=samples.frames, frame_stride=samples.frame_stride, frame_ids=samples.frame_ids,

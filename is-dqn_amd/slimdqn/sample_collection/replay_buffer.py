@@ -91,13 +91,24 @@ class DeviceBatch:
             self._stacks = (st, nx)
         return self._stacks
 
+    def _as_observation(self, stacks):
+        """Vector observations were stored as the bytes of their float32 values (ReplayBuffer._alloc_frame): view them back as
+        (B, d) rows (stack_size 1: the reference's (d, 1) stacks squeezed, architectures/dqn.py:93) or (B, d, stack)."""
+        rb = self._rb
+        if not rb._obs_float:
+            return stacks
+        B = len(self)
+        rows = stacks.reshape(B, rb._w, rb._stack_size).permute(0, 2, 1).reshape(B * rb._stack_size, rb._w).contiguous()
+        f = rows.view(torch.float32).reshape(B, rb._stack_size, rb._w // 4).permute(0, 2, 1)  # (B, d, stack)
+        return f.reshape(B, -1).contiguous() if rb._stack_size == 1 else f.contiguous()
+
     @property
     def state(self):
-        return self._materialize()[0]
+        return self._as_observation(self._materialize()[0])
 
     @property
     def next_state(self):
-        return self._materialize()[1]
+        return self._as_observation(self._materialize()[1])
 
 
 class _MemoryView(Mapping):
@@ -179,11 +190,18 @@ class ReplayBuffer:
         self._traj_maxlen = update_horizon + stack_size
         self._memory = _MemoryView(self)
         self._frames = None
+        self._obs_float = False
         self._h = self._w = self._hw = 0
 
     # ------------------------------------------------------------------ storage
-    def _allocate(self, obs_shape):
-        assert len(obs_shape) == 2, "observations must be single 2-D frames"
+    def _allocate(self, obs_shape, floating: bool = False):
+        # image observations: single 2-D uint8 frames.  Vector observations (LunarLander's (8,) float32, BASELINE configs[0]):
+        # the bytes of the float32 vector are stored as one 1 x 4d "frame", so the same tables, kernels and eviction serve both
+        self._obs_float = bool(floating)
+        if floating:
+            assert len(obs_shape) == 1, "floating-point observations must be vectors"
+            obs_shape = (1, 4 * int(obs_shape[0]))
+        assert len(obs_shape) == 2, "observations must be single 2-D frames (or float vectors)"
         self._h, self._w = int(obs_shape[0]), int(obs_shape[1])
         self._hw = self._h * self._w
         C, s2 = self._max_capacity, 2 * self._stack_size
@@ -224,7 +242,9 @@ class ReplayBuffer:
             slot = self._next_fresh
             self._next_fresh += 1
         obs = np.asarray(observation)
-        if obs.dtype != np.uint8:
+        if self._obs_float:
+            obs = np.ascontiguousarray(obs, dtype=np.float32).view(np.uint8)
+        elif obs.dtype != np.uint8:
             obs = obs.astype(np.uint8)
         self._pending_frames[slot] = obs.reshape(-1).copy()
         return slot
@@ -335,7 +355,8 @@ class ReplayBuffer:
     def accumulate(self, transition: TransitionElement):
         """Yield (frame_ids[2*stack], action, reward, is_terminal) for every element this transition completes."""
         if self._frames is None:
-            self._allocate(np.asarray(transition.observation).shape)
+            first = np.asarray(transition.observation)
+            self._allocate(first.shape, floating=first.ndim == 1 and first.dtype.kind == "f")
         stack, n = self._stack_size, self._update_horizon
         if len(self._trajectory) == self._traj_maxlen:  # deque(maxlen=...) semantics of the reference (:100)
             self._pop_left()

@@ -287,3 +287,65 @@ def test_fc_agent_acting_single_and_batched_match_oracle():
         assert got[i] == want
         if i < 6:
             assert hip.best_action(hip.params, states[i], key=int(heads[i])) == want
+
+
+def test_lunar_lander_shape_training_run_matches_oracle_agent_and_replay():
+    """BASELINE configs[0] end to end on the device: LunarLander-shaped (8,) float32 observations stored in the device replay
+    (the bytes of the vectors as 1 x 32 "frames", stack size 1), sampled, and learned on by the fc [100, 100] K = 1 agent --
+    against the oracle agent fed by the oracle replay on the same seed (the oracle's (8, 1) stacks squeezed as the
+    reference network does, architectures/dqn.py:93)."""
+    from oracle.isdqn import iSDQN as Oracle
+    from oracle.replay_buffer import ReplayBuffer as ORB, TransitionElement as OT
+    from oracle.samplers import UniformSamplingDistribution as OU
+    from slimdqn.networks.isdqn import iSDQN
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+    from tests.gpu_helpers import perturbed_params
+
+    K, A, B, T, utd, feats, obs_dim = 1, 4, 32, 8, 2, (100, 100), (8,)
+    params = perturbed_params(6, obs_dim, feats, "fc", (1 + K) * A, True)
+    hip = iSDQN(0, obs_dim, A, K, list(feats), True, False, "fc", 3e-4, 0.99, 1, utd, T, adam_eps=1e-5, batch_size=B)
+    hip._engine.import_flax(params)
+    ora = Oracle(0, obs_dim, A, K, list(feats), True, False, "fc", 3e-4, 0.99, 1, utd, T, adam_eps=1e-5, params=params)
+    rb = ReplayBuffer(UniformSamplingDistribution(3), B, 200, stack_size=1, update_horizon=1, gamma=0.99)
+    orb = ORB(OU(3), B, 200, stack_size=1, update_horizon=1, gamma=0.99)
+    rng = np.random.default_rng(0)
+    logs_h, logs_o = [], []
+    for step in range(1, 81):
+        obs = rng.normal(size=8).astype(np.float32)
+        a, r, term = int(rng.integers(0, A)), float(rng.normal()), bool(rng.random() < 0.05)
+        rb.add(TransitionElement(obs, a, r, term, term))
+        orb.add(OT(obs, a, r, term, term))
+        if step == 40:  # the device batch is the oracle batch: same keys, same float bits
+            b, ob = rb.sample(), orb.sample()
+            np.testing.assert_array_equal(b.state.cpu().numpy(), np.asarray(ob.state).reshape(B, 8))
+            np.testing.assert_array_equal(b.next_state.cpu().numpy(), np.asarray(ob.next_state).reshape(B, 8))
+            np.testing.assert_array_equal(b.action.cpu().numpy(), np.asarray(ob.action))
+        if step > 40:
+            hip.update_online_params(step, rb)
+            ora.update_online_params(step, orb)
+            uh, lh = hip.update_target_params(step)
+            uo, lo = ora.update_target_params(step)
+            assert uh == uo
+            if uh:
+                logs_h.append(lh)
+                logs_o.append(lo)
+    assert len(logs_h) >= 4
+    for lh, lo in zip(logs_h, logs_o):
+        for k in lh:
+            tol = 1e-3 if lh is logs_h[0] else 5e-3
+            assert abs(lh[k] - lo[k]) < tol * max(1.0, abs(lo[k])), (k, lh[k], lo[k])
+
+
+def test_lunar_lander_entry_point_end_to_end(tmp_path):
+    from experiments.lunar_lander.isdqn import run
+
+    argv = ["-en", "test_ll", "-s", "1", "-dw", "-f", "100", "100", "-rbc", "500", "-bs", "32", "-n", "1", "-horizon", "60", "-at", "fc",
+            "-ne", "2", "-ntspe", "150", "-utd", "1", "-nis", "50", "-ed", "100", "-nbi", "1", "-ln", "-tuf", "20", "-env", "synthetic"]
+    gathered = run(argv, root=str(tmp_path))
+    assert len(gathered) == 2 and gathered[0].shape == (1, 4)
+    out = tmp_path / "lunar_lander" / "exp_output" / "test_ll"
+    params = json.load(open(out / "parameters.json"))
+    assert params["shared_parameters"]["features"] == [100, 100] and params["isdqn"]["n_bellman_iterations"] == 1
+    model = pickle.load(open(out / "isdqn" / "models" / "1", "rb"))
+    assert model["params"]["Dense_0"]["kernel"].shape == (8, 100) and model["params"]["Dense_2"]["kernel"].shape == (100, 2 * 4)
