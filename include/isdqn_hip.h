@@ -249,6 +249,18 @@ int isdqn_net_loss_on_batch_target(const isdqn_net_config* cfg, const float* par
                                    const isdqn_batch* batch, float* losses, float* q_values, float* targets,
                                    void* workspace, void* stream);
 
+/* Gradient of a TD loss, no update: the three gradients AnalysisDQN compares (slimdqn/networks/analysisdqn.py:156-219 --
+ * jax.grad of compute_loss_is / compute_loss_tf / compute_loss_tb).  `grad_out` receives the gradient w.r.t. every parameter
+ * in the internal layout of isdqn_net_param_layout (n_param_floats floats); parameters and optimizer state are untouched.
+ *   n_pairs <= 0 : the configuration's own loss (iS-DQN: online head 1+k on target head k of the same parameters);
+ *   n_pairs  > 0 : online heads online_head + k regressed on target heads target_head + k, k < n_pairs
+ *                  (analysisdqn.py:162-176: head 1 on head 1);
+ *   target_params != NULL : the next states go through `target_params` (compute_loss_tb).
+ * losses[n_pairs or K], q_values / targets [B][n_pairs or K] (may be NULL). */
+int isdqn_net_grad_on_batch(const isdqn_net_config* cfg, const float* params, const float* target_params,
+                            const isdqn_batch* batch, int32_t online_head, int32_t target_head, int32_t n_pairs, float* grad_out,
+                            float* losses, float* q_values, float* targets, void* workspace, void* stream);
+
 /* iSDQN.shift_params (isdqn.py:111-125): head k <- head k+1 on the last Dense; moments untouched. */
 int isdqn_net_shift_params(const isdqn_net_config* cfg, float* params, void* stream);
 

@@ -334,7 +334,7 @@ __device__ __forceinline__ float td_dloss(float d, float huber_delta) {
     return huber_delta > 0.f ? fminf(fmaxf(d, -huber_delta), huber_delta) : 2.f * d;
 }
 constexpr int TD_ROWS = 64;
-__global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, int B, int K, int oh, int A, int nha_p,
+__global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, int B, int K, int oh, int th, int A, int nha_p,
                                                  const int* __restrict__ action, const float* __restrict__ reward,
                                                  const uint8_t* __restrict__ terminal, float gamma_n, float huber_delta,
                                                  float* __restrict__ dout, float* __restrict__ q_values,
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, in
         float d = 0.f, td = 0.f;
         if (on) {
             float qv = q[(int64_t)b * nha_p + (oh + k) * A + a];
-            const float* nq = q + (int64_t)(B + b) * nha_p + k * A;
+            const float* nq = q + (int64_t)(B + b) * nha_p + (th + k) * A;
             float mx = nq[0];
             for (int j = 1; j < A; ++j) mx = fmaxf(mx, nq[j]);
             float tg = r + nt * gamma_n * mx;
@@ -385,12 +385,14 @@ __global__ __launch_bounds__(256) void td_kernel(const float* __restrict__ q, in
             int bl = i / K, k = i - bl * K;
             if (b0 + bl < B) dout[(int64_t)(b0 + bl) * nha_p + (oh + k) * A + s_action[bl]] = s_d[i];
         }
-        // column sums over this workgroup's rows: column (1+k)*A + a' collects rows whose action is a'
+        // column sums over this workgroup's rows: column (oh+k)*A + a' collects rows whose action is a'
+        // (round 3: the regressed heads start at `oh`, which is 0 for the single-head baselines -- the test `head >= 1` left the
+        // head-bias gradient of DQN / of TF-DQN off the head chain at zero)
         for (int c = tid; c < nha_p; c += 256) {
             float sum = 0.f;
             int head = c / A, aa = c - head * A;
-            if (head >= 1 && head <= K)
-                for (int bl = 0; bl < TD_ROWS; ++bl) sum += (s_action[bl] == aa) ? s_d[bl * K + head - 1] : 0.f;
+            if (head >= oh && head < oh + K)
+                for (int bl = 0; bl < TD_ROWS; ++bl) sum += (s_action[bl] == aa) ? s_d[bl * K + head - oh] : 0.f;
             dbh_part[(int64_t)blockIdx.x * nha_p + c] = sum;
         }
     }
@@ -966,7 +968,7 @@ struct AdamTable {
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* __restrict__ p, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ consts, float lr,
                                                    float b1, float b2, float eps, float* __restrict__ grad_out,
-                                                   float* __restrict__ mirror) {
+                                                   float* __restrict__ mirror, int update) {
     // A workgroup covers 16 float4 positions; 16 "slab lanes" per position split the slab reduction (up to a
     // few hundred split-K / per-image-group slabs for the conv kernels) and combine through LDS in a fixed
     // order, so the reduction is deterministic and never a long serial chain of dependent loads.
@@ -1011,6 +1013,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* _
         g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
     }
     if (grad_out != nullptr) *reinterpret_cast<float4*>(grad_out + o) = g;
+    if (!update) return;  // gradient only (isdqn_net_grad_on_batch)
     float* gp = &g.x; float* mp = &pm.x; float* vp = &pv.x; float* xp = &pp.x;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1676,6 +1679,12 @@ extern "C" int isdqn_net_forward(const isdqn_net_config* cfg, const float* param
     return ISDQN_OK;
 }
 
+// Which heads a loss regresses (default: the plan's iterated pairs, online head oh + k on target head k, k < K).  The analysis
+// agents evaluate single-pair losses on the multi-head network: online head 1 on target head 1 (analysisdqn.py:156-183).
+struct HeadSel {
+    int on0, tg0, K;
+};
+
 // Side stream for the weight gradients.  The backward's critical path is dgrad -> LayerNorm-backward -> dgrad ...;
 // every weight gradient only needs its layer's dz and is needed again by Adam at the very end, so they run on a
 // second HIP stream and share the CUs with the data-gradient chain (both sides are partly latency bound and
@@ -1716,7 +1725,7 @@ static int chain(SideStream* ss, hipStream_t signaller, hipStream_t waiter) {
 static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam_m, float* adam_v, int32_t* adam_count,
                          const isdqn_batch* batch, float* losses, float* loss_accum, float* q_values, float* targets,
                          double* priorities, void* workspace, void* stream, bool learn, float* grad_out,
-                         const float* target_params = nullptr) {
+                         const float* target_params = nullptr, const HeadSel* sel = nullptr, bool update = true) {
     int rc;
     const Plan* Pp = cached_plan(cfg, &rc);
     if (!Pp) return rc;
@@ -1727,9 +1736,19 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     rc = check_input(cfg, batch->frames, batch->frame_stride, batch->frame_ids, batch->state);
     if (rc) return rc;
     if (cfg->arch == ISDQN_ARCH_FC) ISDQN_REQUIRE(batch->next_state != nullptr, ISDQN_ERR_ARG, "fc needs next_state");
-    if (learn) ISDQN_REQUIRE(adam_m && adam_v && adam_count, ISDQN_ERR_ARG, "null optimizer state");
+    if (learn && update) ISDQN_REQUIRE(adam_m && adam_v && adam_count, ISDQN_ERR_ARG, "null optimizer state");
+    if (learn && !update) {
+        ISDQN_REQUIRE(grad_out != nullptr, ISDQN_ERR_ARG, "a gradient-only pass needs grad_out");
+        // the optimizer kernels request p / m / v before they know whether they update: a gradient-only pass has no moments, so
+        // those (unused) loads read the parameters instead of a null pointer
+        adam_m = params;
+        adam_v = params;
+    }
     const bool x3 = cfg->precision == ISDQN_PRECISION_BF16X3;
-    const int B = P.B, K = P.K;
+    const int B = P.B, K = sel ? sel->K : P.K;
+    const int on0 = sel ? sel->on0 : P.oh, tg0 = sel ? sel->tg0 : 0;
+    if (sel) ISDQN_REQUIRE(sel->K >= 1 && on0 >= 0 && tg0 >= 0 && on0 + K <= P.n_heads && tg0 + K <= P.n_heads && K <= P.K, ISDQN_ERR_ARG,
+                           "head selection outside the network's heads");
     float* ws = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     NetInput in{batch->frames, batch->frame_stride, batch->frame_ids, B, batch->state, batch->next_state, B};
@@ -1739,7 +1758,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     const Layer& head = P.L[P.n_layers - 1];
     int hc_S = 0, hc_wg = 0;
     static const bool hc_disabled = ISDQN_DEV_ENV("ISDQN_NO_HEAD_CHAIN");
-    if (learn && !hc_disabled && target_params == nullptr && P.n_layers >= 2 && hid.kind == 1 && !hid.is_head && hid.has_relu &&
+    if (learn && update && sel == nullptr && !hc_disabled && target_params == nullptr && P.n_layers >= 2 && hid.kind == 1 && !hid.is_head && hid.has_relu &&
         hid.out_p <= HC_THREADS * HC_MAX_COLS && hid.out_p % 8 == 0) {
         // transitions per workgroup: the per-transition phases scale with S (the kernel is instruction-issue bound) while
         // every workgroup streams the whole head matrix from L2, so S follows the batch: about 256 workgroups
@@ -1842,11 +1861,11 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         }
     } else {
         hipLaunchKernelGGL(td_kernel, dim3(n_blk), dim3(256), 2 * TD_ROWS * K * sizeof(float), st, ws + P.q_off, B, K,
-                           P.oh, P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n, cfg->huber_delta,
+                           on0, tg0, P.n_actions, P.nha_p, batch->action, batch->reward, batch->terminal, cfg->gamma_n, cfg->huber_delta,
                            learn ? ws + P.dout_off : nullptr, qv, tg, priorities, loss_part, dbh_part);
         ISDQN_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(ceil_div(K, 16) + ceil_div(P.nha_p, 16)), dim3(256), 0, st, loss_part, dbh_part, n_blk, B, K, P.nha_p,
-                           losses, loss_accum, learn ? ws + P.dbh_off : nullptr, learn ? adam_count : nullptr,
+                           losses, loss_accum, learn ? ws + P.dbh_off : nullptr, (learn && update) ? adam_count : nullptr,
                            cfg->adam_b1, cfg->adam_b2, adam_consts);
         ISDQN_HIP_CHECK(hipGetLastError());
     }
@@ -2061,11 +2080,11 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                                          : MatSrc{act_in, l.in_p, B, l.in_p, 1};
             w_slabs = effective_splits(B, l.gw_slabs);
             if (w_slabs == 1 && !l.in_unpadded_ld) {
-                fused_adam = true;
+                fused_adam = true;  // (a gradient-only pass runs the same kernel with the stores of p / m / v switched off)
 
                 AdamFuse af{params + l.w_off, adam_m + l.w_off, adam_v + l.w_off, ws + P.adam_tab_off,
                             cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps,
-                            grad_out ? grad_out + l.w_off : nullptr, ws + P.wsplit_off + l.w_off};
+                            grad_out ? grad_out + l.w_off : nullptr, ws + P.wsplit_off + l.w_off, update ? 1 : 0};
                 // 64x64 tiles: the contraction is only B deep, the kernel lives off streaming p/m/v through the Adam
                 // epilogue, and 128x128 tiles would leave 100 workgroups for 256 CUs
                 // (operands: dz of a hidden layer -- or the fp32 dL/dq of the head -- and the S8 activations below it)
@@ -2102,7 +2121,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     auto run_adam = [&](const AdamTable& tab, hipStream_t s2) -> int {
         if (tab.n == 0) return ISDQN_OK;
         hipLaunchKernelGGL(adam_kernel, dim3(tab.total_blocks), dim3(256), 0, s2, tab, params, adam_m, adam_v, ws + P.adam_tab_off,
-                           cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps, grad_out, ws + P.wsplit_off);
+                           cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps, grad_out, ws + P.wsplit_off, update ? 1 : 0);
         ISDQN_HIP_CHECK(hipGetLastError());
         return ISDQN_OK;
     };
@@ -2153,6 +2172,19 @@ extern "C" int isdqn_net_loss_on_batch(const isdqn_net_config* cfg, const float*
                                        float* losses, float* q_values, float* targets, void* workspace, void* stream) {
     return learn_or_loss(cfg, const_cast<float*>(params), nullptr, nullptr, nullptr, batch, losses, nullptr, q_values,
                          targets, nullptr, workspace, stream, false, nullptr);
+}
+
+// Gradient of a TD loss without an update (the diagnostics of AnalysisDQN, analysisdqn.py:156-219): `n_pairs` > 0 regresses
+// online heads online_head + k on target heads target_head + k (k < n_pairs) instead of the plan's iterated pairs;
+// `target_params` != NULL takes the next states through those parameters (the target-based loss).
+extern "C" int isdqn_net_grad_on_batch(const isdqn_net_config* cfg, const float* params, const float* target_params,
+                                       const isdqn_batch* batch, int32_t online_head, int32_t target_head, int32_t n_pairs,
+                                       float* grad_out, float* losses, float* q_values, float* targets, void* workspace,
+                                       void* stream) {
+    ISDQN_REQUIRE(grad_out != nullptr, ISDQN_ERR_ARG, "null grad_out");
+    HeadSel sel{online_head, target_head, n_pairs};
+    return learn_or_loss(cfg, const_cast<float*>(params), nullptr, nullptr, nullptr, batch, losses, nullptr, q_values, targets, nullptr,
+                         workspace, stream, true, grad_out, target_params, n_pairs > 0 ? &sel : nullptr, false);
 }
 
 // DQN.learn_on_batch / loss_on_batch (dqn.py:59-83): separate target parameters for the next states.

@@ -81,6 +81,7 @@ struct AdamFuse {
     float lr, b1, b2, eps;
     float* grad_out;         // optional: also store the raw gradient (tests)
     float* mirror;           // S8 mirror of p (same layout): the updated parameters are written in both forms
+    int update;              // 0: gradient only (grad_out), p / m / v / mirror untouched
 };
 
 // S8M: bit 0 / bit 1 = operand A / B is stored S8 (gemm_core.h): staged by copy; such an operand is always chunk-aligned.
@@ -200,8 +201,8 @@ struct PlainGemm {
                     nv[r] = vv;
                     np[r] = pp[it][r] - adam.lr * ((mm / c1) / (sqrtf(vv / c2) + adam.eps));
                 }
-                if (on[it]) {
-                    if (adam.grad_out) *reinterpret_cast<float4*>(adam.grad_out + off[it]) = g;
+                if (on[it] && adam.grad_out) *reinterpret_cast<float4*>(adam.grad_out + off[it]) = g;
+                if (on[it] && adam.update) {
                     *reinterpret_cast<f32x4*>(adam.m + off[it]) = nm;
                     *reinterpret_cast<f32x4*>(adam.v + off[it]) = nv;
                     *reinterpret_cast<f32x4*>(adam.p + off[it]) = np;

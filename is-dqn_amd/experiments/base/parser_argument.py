@@ -69,5 +69,13 @@ def add_tfdqn_arguments(parser: argparse.ArgumentParser) -> List[str]:
     return _add(parser, _TFDQN)
 
 
+def add_analysisdqn_arguments(parser: argparse.ArgumentParser) -> List[str]:
+    return _add(parser, _ISDQN)  # (parser_argument.py: the analysis agents take their base agents' flags)
+
+
+def add_analysistfdqn_arguments(parser: argparse.ArgumentParser) -> List[str]:
+    return _add(parser, _TFDQN)
+
+
 def add_engine_arguments(parser: argparse.ArgumentParser) -> List[str]:
     return _add(parser, _ENGINE)

@@ -265,6 +265,23 @@ class QNetEngine:
         self._mirror_made_current()  # Adam wrote the updated weights in both forms
         return self.losses
 
+    def grad_on_batch(self, batch: _hip.Batch, grad_out: torch.Tensor, target_params: torch.Tensor | None = None, online_head: int = 0,
+                      target_head: int = 0, n_pairs: int = 0, params=None) -> torch.Tensor:
+        """Gradient of a TD loss into ``grad_out`` (internal layout), nothing updated (analysisdqn.py:156-219): the
+        configuration's own loss (n_pairs = 0) or online heads online_head + k on target heads target_head + k; next states
+        through ``target_params`` when given.  Returns the device tensor of the loss per pair (the first n_pairs / K entries)."""
+        p = self.params if params is None else params
+        _hip.check(
+            self.lib.isdqn_net_grad_on_batch(
+                ctypes.byref(self.cfg), _hip.ptr(p), _hip.ptr(target_params), ctypes.byref(batch), int(online_head), int(target_head),
+                int(n_pairs), _hip.ptr(grad_out), _hip.ptr(self.losses), _hip.ptr(self.q_values), _hip.ptr(self.targets),
+                _hip.ptr(self.workspace), _hip.stream_ptr(self.device),
+            ),
+            "isdqn_net_grad_on_batch",
+        )
+        self._mirror_holds(params)
+        return self.losses
+
     def learn_on_batch_target(self, batch: _hip.Batch, target_params: torch.Tensor) -> torch.Tensor:
         """DQN step (dqn.py:59-72): next states through `target_params`, in-place update of the online parameters."""
         _hip.check(

@@ -137,6 +137,10 @@ _SIGNATURES = {
         c_int32,
         [POINTER(NetConfig), c_void_p, c_void_p, POINTER(Batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "isdqn_net_grad_on_batch": (
+        c_int32,
+        [POINTER(NetConfig), c_void_p, c_void_p, POINTER(Batch), c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "isdqn_net_shift_params": (c_int32, [POINTER(NetConfig), c_void_p, c_void_p]),
     "isdqn_net_best_action": (
         c_int32,

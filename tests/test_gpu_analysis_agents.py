@@ -1,0 +1,145 @@
+"""GPU parity of the analysis agents (reference slimdqn/networks/analysisdqn.py:123-219,
+analysistfdqn.py:81-118) against the oracle restatement: the three gradients (iS, target-free, target-based: gradient-only
+passes of the library, isdqn_net_grad_on_batch), their cosine similarities, the target churn on the training and on the
+evaluation batch, the step itself, the trainer cadence and the entry points."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FEATS = (8, 12, 16, 24)
+
+
+def _pair(K=3, A=5, B=16, lr=1e-3):
+    from oracle.analysisdqn import AnalysisDQN as Oracle
+    from slimdqn.networks.analysisdqn import AnalysisDQN
+    from tests.gpu_helpers import perturbed_params
+
+    params = perturbed_params(4, (84, 84, 4), FEATS, "cnn", (1 + K) * A, True)
+    hip = AnalysisDQN(0, (84, 84, 4), A, K, list(FEATS), True, False, "cnn", lr, 0.99, 1, 1, 6, adam_eps=1.5e-4, batch_size=B)
+    hip._engine.import_flax(params)
+    ora = Oracle(0, (84, 84, 4), A, K, list(FEATS), True, False, "cnn", lr, 0.99, 1, 1, 6, adam_eps=1.5e-4, params=params)
+    # a target copy that differs from the online parameters (as it does between two target updates)
+    rng = np.random.default_rng(1)
+    bumped = {m: {n: (v + 0.02 * rng.normal(size=v.shape)).astype(np.float32) for n, v in l.items()} for m, l in params.items()}
+    hip._engine.import_flax(bumped, target=hip.target_params.tensor)
+    from oracle import network as onet
+
+    ora.target_params = onet.to_torch(bumped)
+    return hip, ora
+
+
+def _batches(B, A, seeds=(11, 12)):
+    from tests.gpu_helpers import make_frame_batch
+
+    out = []
+    for s in seeds:
+        frames, ids, action, reward, terminal, ref = make_frame_batch(B, A, seed=s)
+        out.append(ref)
+    return out
+
+
+def test_three_gradients_cosines_and_churn_match_the_oracle():
+    K, A, B = 3, 5, 16
+    hip, ora = _pair(K, A, B)
+    train, ev = _batches(B, A)
+    # gradients leaf by leaf
+    g_is, g_tf, g_tb = hip.three_gradients(hip.params, hip.target_params, train)
+    o_is, o_tf, o_tb = ora.three_gradients(ora.params, ora.target_params, train)
+    eng = hip._engine
+    for name, g, o in (("is", g_is, o_is), ("tf", g_tf, o_tf), ("tb", g_tb, o_tb)):
+        got = eng.internal_to_flax_grads(g)
+        for mod in o:
+            for leaf in o[mod]:
+                a, b = np.asarray(got[mod][leaf], np.float64), o[mod][leaf].numpy().astype(np.float64)
+                assert np.linalg.norm(a - b) <= 2e-3 * max(np.linalg.norm(b), 1e-6), (name, mod, leaf)
+        # single-pair losses touch head 1 only: the other head columns of the last Dense have exactly zero gradient
+        if name != "is":
+            k = np.asarray(got["Dense_1"]["kernel"])
+            assert np.abs(k[:, :A]).max() == 0 and np.abs(k[:, 2 * A :]).max() == 0 and np.abs(k[:, A : 2 * A]).max() > 0
+    # nothing was updated by the gradient-only passes
+    assert int(eng.adam_count.item()) == 0 and float(eng.adam_m.abs().max()) == 0.0
+    # the diagnostics of one learn step
+    before = eng.params.clone()
+    _, _, losses, ct, ce, c_is, c_tf = hip.learn_on_batch(hip.params, hip.target_params, hip.optimizer_state, train, ev)
+    _, _, o_losses, o_ct, o_ce, o_c_is, o_c_tf = ora.learn_on_batch(ora.params, ora.target_params, ora.optimizer_state, train, ev)
+    assert not torch.equal(before, eng.params) and int(eng.adam_count.item()) == 1
+    np.testing.assert_allclose(losses.cpu().numpy(), o_losses, rtol=1e-3, atol=1e-3)
+    assert abs(c_is - o_c_is) < 2e-3 and abs(c_tf - o_c_tf) < 2e-3, (c_is, o_c_is, c_tf, o_c_tf)
+    assert abs(c_is) < 0.999 and abs(c_tf) < 0.999  # (the three gradients really differ)
+    # churn = |delta target| after ONE Adam step of size lr: compare in units of the oracle's churn
+    np.testing.assert_allclose(ct, o_ct, rtol=0.05, atol=2e-4)
+    np.testing.assert_allclose(ce, o_ce, rtol=0.05, atol=2e-4)
+    assert (o_ct > 0).all() and (o_ce > 0).all()
+
+
+def test_trainer_cadence_and_logs_match_the_oracle():
+    from oracle.replay_buffer import ReplayBuffer as ORB, TransitionElement as OT
+    from oracle.samplers import UniformSamplingDistribution as OU
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+
+    K, A, B = 2, 4, 8
+    hip, ora = _pair(K, A, B, lr=2e-4)
+    rb = ReplayBuffer(UniformSamplingDistribution(3), B, 100, update_horizon=1, gamma=0.99)
+    orb = ORB(OU(3), B, 100, update_horizon=1, gamma=0.99)
+    rng = np.random.default_rng(0)
+    logs_h, logs_o = [], []
+    for step in range(1, 31):
+        obs = rng.integers(0, 256, (84, 84), dtype=np.uint8)
+        a, r, term = int(rng.integers(0, A)), float(rng.choice([-1.0, 0.0, 1.0])), bool(rng.random() < 0.05)
+        rb.add(TransitionElement(obs, a, r, term, term))
+        orb.add(OT(obs, a, r, term, term))
+        if step > 12:
+            hip.update_online_params(step, rb)   # two samples per update: train, then eval (analysisdqn.py:65-66)
+            ora.update_online_params(step, orb)
+            uh, lh = hip.update_target_params(step)
+            uo, lo = ora.update_target_params(step)
+            assert uh == uo
+            if uh:
+                logs_h.append(lh)
+                logs_o.append(lo)
+    assert len(logs_h) == 3
+    for lh, lo in zip(logs_h, logs_o):
+        assert lh.keys() == lo.keys()
+        for k in lh:
+            tol = 2e-2 if ("churn" in k or "cosine" in k) else 5e-3
+            assert abs(lh[k] - lo[k]) < tol * max(1.0, abs(lo[k])) or abs(lh[k] - lo[k]) < 3e-4, (k, lh[k], lo[k])
+    # the target copy is the pre-shift parameters of the last target update
+    assert not torch.equal(hip.target_params.tensor, hip.params.tensor)
+
+
+def test_analysis_tfdqn_churn_matches_the_oracle():
+    from oracle.analysisdqn import AnalysisTFDQN as Oracle
+    from slimdqn.networks.analysistfdqn import AnalysisTFDQN
+    from tests.gpu_helpers import perturbed_params
+
+    A, B = 5, 16
+    params = perturbed_params(4, (84, 84, 4), FEATS, "cnn", A, True)
+    hip = AnalysisTFDQN(0, (84, 84, 4), A, list(FEATS), True, False, "cnn", 1e-3, 0.99, 1, 1, 6, adam_eps=1.5e-4, batch_size=B)
+    hip._engine.import_flax(params)
+    ora = Oracle(0, (84, 84, 4), A, list(FEATS), True, False, "cnn", 1e-3, 0.99, 1, 1, 6, adam_eps=1.5e-4, params=params)
+    train, ev = _batches(B, A)
+    _, _, loss, ct, ce = hip.learn_on_batch(hip.params, hip.optimizer_state, train, ev)
+    _, _, o_loss, o_ct, o_ce = ora.learn_on_batch(ora.agent.params, ora.agent.optimizer_state, train, ev)
+    assert abs(float(loss) - float(o_loss)) < 1e-3 * max(1.0, abs(float(o_loss)))
+    assert abs(ct - o_ct) < 0.05 * o_ct + 2e-4 and abs(ce - o_ce) < 0.05 * o_ce + 2e-4 and o_ct > 0 and o_ce > 0
+
+
+@pytest.mark.parametrize("algo", ["analysisdqn", "analysistfdqn"])
+def test_analysis_entry_points_end_to_end(tmp_path, algo):
+    import importlib
+
+    run = importlib.import_module(f"experiments.atari.{algo}").run
+    argv = ["-en", "ana_Synthetic", "-s", "1", "-dw", "-f", "8", "8", "8", "16", "-rbc", "200", "-bs", "8", "-n", "1", "-horizon", "30", "-at", "cnn",
+            "-ne", "1", "-ntspe", "60", "-utd", "4", "-nis", "20", "-ed", "100", "-ln", "-tuf", "16", "-env", "synthetic"]
+    if algo == "analysisdqn":
+        argv += ["-nbi", "2"]
+    gathered = run(argv, root=str(tmp_path))
+    assert len(gathered) == 1
+    out = tmp_path / "atari" / "exp_output" / "ana_Synthetic"
+    assert json.load(open(out / "parameters.json"))[algo]["target_update_frequency"] == 16
+    assert (out / algo / "models" / "1").exists()

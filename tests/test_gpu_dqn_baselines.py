@@ -153,3 +153,43 @@ def test_entry_points_end_to_end_on_synthetic_env(algo, tmp_path):
     assert algo in stored and "target_update_frequency" in stored[algo] and "n_bellman_iterations" not in stored[algo]
     assert os.path.exists(os.path.join(base, algo, "episode_returns_and_lengths", "1.json"))
     assert os.path.exists(os.path.join(base, algo, "models", "1"))
+
+
+@pytest.mark.parametrize("kind", ["tfdqn", "dqn"])
+def test_every_leaf_gradient_of_the_single_head_losses_matches_the_oracle(kind):
+    """Leaf-by-leaf gradients of the single-head losses through the library's gradient-only pass (isdqn_net_grad_on_batch),
+    which takes the td_kernel route for both baselines.  Round 3 regression: that route left the head-BIAS gradient at zero
+    whenever the regressed heads start at head 0 (DQN always; TF-DQN off the head chain) -- three lr-sized Adam steps could
+    not show it, a gradient comparison does."""
+    feats, A, B = (7, 9, 11, 13), 5, 12
+    hip, ora, params = _agents(kind, feats, A, B)
+    frames, ids, action, reward, terminal, ref = make_frame_batch(B, A, seed=31, n_frames=B + 40)
+    eng = hip._engine
+    batch = _hip_batch(hip, frames, ids, action, reward, terminal)
+    g = torch.zeros_like(eng.params)
+    if kind == "dqn":
+        bumped = {m: {n: (v + 0.01 * np.random.default_rng(1).normal(size=v.shape)).astype(np.float32) for n, v in l.items()}
+                  for m, l in params.items()}
+        eng.import_flax(bumped)
+        from oracle import network as onet
+
+        ora.params = onet.to_torch(bumped)
+        eng.grad_on_batch(batch, g, target_params=hip.target_params.tensor)
+        o_grads, _ = ora.grads(ora.params, ora.target_params, ref)
+    else:
+        eng.grad_on_batch(batch, g)
+        o_grads, _ = ora.grads(ora.params, ref)
+    got = eng.internal_to_flax_grads(g)
+    for mod in o_grads:
+        for leaf in o_grads[mod]:
+            a, b = np.asarray(got[mod][leaf], np.float64), o_grads[mod][leaf].numpy().astype(np.float64)
+            assert np.linalg.norm(b) > 0
+            assert np.linalg.norm(a - b) <= 2e-3 * np.linalg.norm(b), (kind, mod, leaf, np.linalg.norm(a), np.linalg.norm(b))
+    assert int(eng.adam_count.item()) == 0  # gradient only
+    # and the update path agrees with its own gradient: one DQN step moves the head bias (it did not before the fix)
+    before = eng.export_flax()["Dense_1"]["bias"].copy()
+    if kind == "dqn":
+        eng.learn_on_batch_target(batch, hip.target_params.tensor)
+        after = eng.export_flax()["Dense_1"]["bias"]
+        big = np.abs(o_grads["Dense_1"]["bias"].numpy()) > 1e-3
+        assert big.any() and (np.abs(after - before)[big] > 0.5e-3).all()
