@@ -1,0 +1,23 @@
+"""Bank-conflict check of the weights-stationary LDS image (csrc/conv_ws.h: ws_slot): 64-byte rows, 16-byte chunk c of row r
+in slot c ^ X[(r >> 2) & 3].  ds_read_b128 is served in four 16-lane groups (MI355X_MICROARCH.md, LDS); a group is
+conflict-free when its 16 lanes touch 16 different bank quads (16-byte units of the 256-byte LDS line)."""
+GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+          list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)), list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+
+
+def worst(X):
+    w = 0
+    for lanes in GROUPS:
+        quads = {}
+        for l in lanes:
+            row, chunk = l & 15, l >> 4
+            q = ((row * 64 + (chunk ^ X[(row >> 2) & 3]) * 16) // 16) % 16
+            quads[q] = quads.get(q, 0) + 1
+        w = max(w, max(quads.values()))
+    return w
+
+
+if __name__ == "__main__":
+    print("plain 64-byte rows:", worst([0, 0, 0, 0]), "-way")
+    print("X = {0, 2, 3, 1}  :", worst([0, 2, 3, 1]), "-way")
+    assert worst([0, 2, 3, 1]) == 1
