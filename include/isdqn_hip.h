@@ -135,6 +135,7 @@ int isdqn_replay_deinterleave(const uint8_t* state, const uint8_t* next_state, i
 /* ========================================================================== */
 #define ISDQN_ARCH_CNN 0 /* dqn.py:48-74  three SAME convs (8s4, 4s2, 3s1) + dense stack */
 #define ISDQN_ARCH_FC 1  /* dqn.py:89-103 dense stack only                               */
+#define ISDQN_ARCH_IMPALA 2 /* dqn.py:7-36, 75-88  three Stacks (conv3x3, max-pool 3x3/2, two residual blocks) + dense stack */
 #define ISDQN_MAX_FEATURES 8
 
 #define ISDQN_PRECISION_BF16X3 0 /* split-bf16 MFMA (hi*hi + lo*hi + hi*lo), fp32 accumulate: ~2^-17 */

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 #include <atomic>
 
 #include "conv_img.h"
@@ -1396,6 +1397,9 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const float* 
     return ISDQN_OK;
 }
 
+static int impala_forward(const Plan& P, bool x3, const float* params, const float* wmir, const NetInput& in, int n_img, int z_img,
+                          float* ws, hipStream_t st);  // impala.h
+
 // forward over n_img images; hidden activations -> ws act regions, head output -> q_out [n_img][nha_p]
 static int net_forward(const Plan& P, bool x3, const float* params, const NetInput& in, int n_img, int z_img,
                        float* ws, float* q_out, hipStream_t st, int n_run = -1, int skip_post_layer = -1) {
@@ -1407,7 +1411,9 @@ static int net_forward(const Plan& P, bool x3, const float* params, const NetInp
         float* act = l.is_head ? q_out : ws + l.act_off;
         float* z = l.is_head ? nullptr : ws + l.z_off;
         int rc;
-        if (l.kind == 0)
+        if (l.kind == 2)
+            rc = impala_forward(P, x3, params, wmir, in, n_img, z_img, ws, st);
+        else if (l.kind == 0)
             rc = conv_fwd(l, x3, params, wmir, in, prev, n_img, z_img, act, z, st);
         else
             rc = dense_fwd(l, x3, params, wmir, in, prev, n_img, l.is_head ? 0 : z_img, ws + P.slab_off, act, z, st,
@@ -1679,6 +1685,8 @@ static int conv_wgrad_slabs(const Layer& l, int n_img) {
     return ceil_div(ksteps, sps);
 }
 
+#include "impala.h"
+
 }  // namespace isdqn
 
 using namespace isdqn;
@@ -1707,6 +1715,29 @@ extern "C" int isdqn_net_param_layout(const isdqn_net_config* cfg, int64_t* n_pa
     };
     for (int i = 0; i < P.n_layers; ++i) {
         const Layer& l = P.L[i];
+        if (l.kind == 2) {  // impala torso: Stack_s / {Conv_k, LayerNorm_b} (Flax nests the Stack's modules: "Stack_0/Conv_1/kernel")
+            for (int s = 0; s < IMP_STACKS; ++s) {
+                const ImpalaStack& S = P.imp[s];
+                char mod[40];
+                for (int k = 0; k < IMP_CONVS; ++k) {
+                    const Layer& c = S.conv[k];
+                    if (k >= 1 && (k & 1) && S.ln_g[(k - 1) / 2] >= 0) {  // LayerNorm_b sits in front of Conv_{1+2b}
+                        const int b = (k - 1) / 2;
+                        snprintf(mod, sizeof(mod), "Stack_%d/LayerNorm_%d", s, b);
+                        add(mod, "scale", S.ln_g[b], S.C_p, 3, i, 1, S.C, 0, 0, 0, S.C_p, 0, 0);
+                        add(mod, "bias", S.ln_b[b], S.C_p, 4, i, 1, S.C, 0, 0, 0, S.C_p, 0, 0);
+                    }
+                    snprintf(mod, sizeof(mod), "Stack_%d/%s", s, c.name);
+                    add(mod, "kernel", c.w_off, c.w_size, 0, i, 4, 3, 3, c.cin, c.cout, c.cout_p, c.taps, c.cin_p);
+                    add(mod, "bias", c.b_off, c.out_p, 2, i, 1, c.cout, 0, 0, 0, c.out_p, 0, 0);
+                }
+            }
+            if (l.has_ln) {
+                add(l.ln_name, "scale", l.g_off, l.out_p, 3, i, 1, l.out_f, 0, 0, 0, l.out_p, 0, 0);
+                add(l.ln_name, "bias", l.be_off, l.out_p, 4, i, 1, l.out_f, 0, 0, 0, l.out_p, 0, 0);
+            }
+            continue;
+        }
         if (l.kind == 0) {
             add(l.name, "kernel", l.w_off, l.w_size, 0, i, 4, l.ksz, l.ksz, l.cin, l.cout, l.cout_p, l.is_u8 ? l.cin : l.taps,
                 l.is_u8 ? 64 : l.cin_p);
@@ -1750,8 +1781,8 @@ extern "C" int isdqn_net_workspace_region(const isdqn_net_config* cfg, const cha
 
 static int check_input(const isdqn_net_config* cfg, const uint8_t* frames, int64_t frame_stride,
                        const int32_t* frame_ids, const float* obs) {
-    if (cfg->arch == ISDQN_ARCH_CNN) {
-        ISDQN_REQUIRE(frames && frame_ids, ISDQN_ERR_ARG, "cnn needs frames and frame_ids");
+    if (cfg->arch != ISDQN_ARCH_FC) {
+        ISDQN_REQUIRE(frames && frame_ids, ISDQN_ERR_ARG, "cnn / impala need frames and frame_ids");
         ISDQN_REQUIRE(frame_stride >= (int64_t)cfg->obs_h * cfg->obs_w, ISDQN_ERR_SHAPE, "frame_stride < h*w");
     } else {
         ISDQN_REQUIRE(obs != nullptr, ISDQN_ERR_ARG, "fc needs obs");
@@ -1881,7 +1912,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
     if (target_params != nullptr) {
         // DQN (dqn.py:74-88): the next states go through the TARGET parameters, the states through the online ones: two
         // forwards of B images each over the same workspace, q rows [B, 2B) first, then rows [0, B) (+ z of every layer)
-        const int stack = cfg->arch == ISDQN_ARCH_CNN ? cfg->obs_c : 0;
+        const int stack = cfg->arch != ISDQN_ARCH_FC ? cfg->obs_c : 0;
         NetInput nx{batch->frames, batch->frame_stride, batch->frame_ids, 0, batch->next_state, nullptr, 0, 2 * stack, stack};
         rc = refresh_mirror(P, target_params, ws, st);
         if (rc) return rc;
@@ -2044,10 +2075,10 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                     add_entry(l.g_off, l.out_p, ws + l.red_off, 1, 0);
                     add_entry(l.be_off, l.out_p, ws + l.red_off + l.out_p, 1, 0);
                 }
-                add_entry(l.b_off, l.out_p, ws + l.red_off + 2 * l.out_p, 1, 0);
+                if (l.b_off >= 0) add_entry(l.b_off, l.out_p, ws + l.red_off + 2 * l.out_p, 1, 0);  // (the impala torso has no bias of its own)
             } else {
                 // da (w.r.t. this layer's activation) was left in ws+da_off by layer i+1's data-gradient
-                int rows = l.kind == 0 ? B * l.npix : B;
+                int rows = l.kind != 1 ? B * l.npix : B;
                 int nb = 0;
                 rc = ln_bwd(l, params, ws + P.da_off, ws + l.z_off, rows, ws + l.dz_off, ws + l.part_off, &nb, st);
                 if (rc) return rc;
@@ -2055,10 +2086,15 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                     add_entry(l.g_off, l.out_p, ws + l.part_off, nb, 3 * (int64_t)l.out_p);
                     add_entry(l.be_off, l.out_p, ws + l.part_off + l.out_p, nb, 3 * (int64_t)l.out_p);
                 }
-                add_entry(l.b_off, l.out_p, ws + l.part_off + 2 * l.out_p, nb, 3 * (int64_t)l.out_p);
+                if (l.b_off >= 0) add_entry(l.b_off, l.out_p, ws + l.part_off + 2 * l.out_p, nb, 3 * (int64_t)l.out_p);
             }
         } else {
             add_entry_on(hc_S && ss ? 1 : 0, l.b_off, l.out_p, ws + P.dbh_off, 1, 0);  // loss_finalize_kernel's stream
+        }
+        if (l.kind == 2) {  // the impala torso: its own backward (generic engine + row-wise kernels) and optimizer launches, on the caller's stream
+            rc = impala_backward(P, cfg, x3, params, adam_m, adam_v, wmir, ws, B, grad_out, update, st);
+            if (rc) return rc;
+            continue;
         }
         // Weight gradients of the middle layers go to the side stream.  Every fork costs the main stream an event
         // record (a ~6 us bubble), so the head's tiny weight gradient and the first layer's (nothing is left to
@@ -2086,7 +2122,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 if (!dz_fused) rc = conv_dgrad_img(l, P.L[i - 1], x3, params, wmir, dz_cur, ws, B, st, &dz_fused, &red_jobs);
                 if (rc) return rc;
             }
-            if (l.kind == 1 && P.L[i - 1].kind == 0 && P.L[i - 1].cout_p == 64 && !l.in_unpadded_ld &&
+            if (l.kind == 1 && P.L[i - 1].kind != 1 && P.L[i - 1].cout_p == 64 && !l.in_unpadded_ld &&
                 P.L[i - 1].part_rows >= ceil_div(B, 128) * P.L[i - 1].npix) {
                 // first dense layer over a 64-channel conv output: data gradient + LN/ReLU backward in one kernel
                 const Layer& below = P.L[i - 1];
@@ -2385,7 +2421,7 @@ extern "C" int isdqn_net_analysis_layout(const isdqn_net_config* cfg, int32_t* n
     *n_hidden = P.n_layers - 1;
     for (int i = 0; i < P.n_layers - 1 && sizes != nullptr && i < max_sizes; ++i) {
         const Layer& l = P.L[i];
-        sizes[i] = l.kind == 0 ? (int64_t)l.npix * l.cout : (int64_t)l.out_f;
+        sizes[i] = l.kind != 1 ? (int64_t)l.npix * l.cout : (int64_t)l.out_f;
     }
     return ISDQN_OK;
 }
@@ -2412,12 +2448,12 @@ extern "C" int isdqn_net_analysis(const isdqn_net_config* cfg, const float* para
     int64_t off = 0;
     for (int i = 0; i < P.n_layers - 1; ++i) {
         const Layer& l = P.L[i];
-        const int cpp = l.kind == 0 ? l.cout_p : l.out_p, c = l.kind == 0 ? l.cout : l.out_f;
+        const int cpp = l.kind != 1 ? l.cout_p : l.out_p, c = l.kind != 1 ? l.cout : l.out_f;
         const bool last = i == P.n_layers - 2;
         hipLaunchKernelGGL(act_rowsum_kernel, dim3(ceil_div(l.out_elems_p, 256)), dim3(256), 0, st, ws + l.act_off, n_rows, l.out_elems_p,
-                           cpp, c, scores_out + off, last ? features_out : nullptr, last ? (l.kind == 0 ? l.npix * l.cout : l.out_f) : 0);
+                           cpp, c, scores_out + off, last ? features_out : nullptr, last ? (l.kind != 1 ? l.npix * l.cout : l.out_f) : 0);
         ISDQN_HIP_CHECK(hipGetLastError());
-        off += l.kind == 0 ? (int64_t)l.npix * l.cout : (int64_t)l.out_f;
+        off += l.kind != 1 ? (int64_t)l.npix * l.cout : (int64_t)l.out_f;
     }
     return ISDQN_OK;
 }

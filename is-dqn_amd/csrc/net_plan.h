@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -45,7 +46,23 @@ struct Layer {
     char ln_name[16];
 };
 
+// Impala torso (architectures/dqn.py:7-36, 75-88): three Stacks.  The torso is ONE pseudo-layer (kind 2) of the layer list -- its
+// output (the residual stream behind Stack_2, LayerNorm + ReLU + flatten) has the geometry of a conv layer's output, so the dense
+// tail, the head chain and the fused dense data gradient treat it exactly like the cnn torso's last convolution; what is inside
+// runs on the generic MFMA engine (ConvFwd / ConvDgrad / ConvWgrad problems) and a few row-wise kernels (impala.h).
+constexpr int IMP_STACKS = 3, IMP_CONVS = 5;
+struct ImpalaStack {
+    int H, W, Hp, Wp, pool_pad;     // the first conv runs at H x W, everything behind the max-pool at Hp x Wp
+    int cin, cin_p, C, C_p;
+    Layer conv[IMP_CONVS];           // Conv_0 (cin -> C at H x W), Conv_1 .. Conv_4 (C -> C at Hp x Wp): geometry, parameter and slab offsets
+    int64_t ln_g[2], ln_b[2];        // LayerNorm_0 / LayerNorm_1 of the two residual blocks (-1: no LayerNorm)
+    // workspace (float offsets; rows of N2 images in the forward, B in the backward)
+    int64_t xin_off, z0_off, arg_off, r_off[3], a1_off[2], a2_off[2], zt_off;
+    int64_t dr_off, da_off, dzs_off, dz0_off, bpart_off[IMP_CONVS], lnpart_off[2];
+};
+
 struct Plan {
+    ImpalaStack imp[IMP_STACKS];
     int n_layers;
     Layer L[MAX_LAYERS];
     int B, N2;
@@ -72,9 +89,9 @@ static inline void same_padding(int size, int k, int s, int& out, int& lo) {
 
 static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
     ISDQN_REQUIRE(cfg != nullptr, ISDQN_ERR_ARG, "null config");
-    ISDQN_REQUIRE(cfg->arch == ISDQN_ARCH_CNN || cfg->arch == ISDQN_ARCH_FC, ISDQN_ERR_UNSUPPORTED,
-                  "architecture_type must be cnn or fc (impala is outside the hot-path scope)");
-    ISDQN_REQUIRE(cfg->n_features >= (cfg->arch == ISDQN_ARCH_CNN ? 3 : 0) && cfg->n_features <= ISDQN_MAX_FEATURES,
+    ISDQN_REQUIRE(cfg->arch == ISDQN_ARCH_CNN || cfg->arch == ISDQN_ARCH_FC || cfg->arch == ISDQN_ARCH_IMPALA, ISDQN_ERR_UNSUPPORTED,
+                  "architecture_type must be cnn, impala or fc");
+    ISDQN_REQUIRE(cfg->n_features >= (cfg->arch == ISDQN_ARCH_FC ? 0 : 3) && cfg->n_features <= ISDQN_MAX_FEATURES,
                   ISDQN_ERR_ARG, "bad n_features");
     ISDQN_REQUIRE(cfg->n_actions >= 1 && cfg->n_heads >= 1, ISDQN_ERR_ARG, "need n_actions >= 1 and n_heads >= 1");
     ISDQN_REQUIRE(cfg->batch_size >= 1 && cfg->batch_size <= 4096, ISDQN_ERR_ARG, "batch_size must be in [1, 4096]");
@@ -147,13 +164,87 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
         in_elems_p = h * w * c_p;
         in_f = h * w * c;
         in_p = in_elems_p;
+    } else if (cfg->arch == ISDQN_ARCH_IMPALA) {
+        ISDQN_REQUIRE(cfg->obs_h >= 8 && cfg->obs_w >= 8 && cfg->obs_c >= 1 && cfg->obs_c <= 8, ISDQN_ERR_ARG, "bad observation shape");
+        int h = cfg->obs_h, w = cfg->obs_w, c = cfg->obs_c, c_p = 8;
+        auto conv3 = [&](Layer& l, int hh, int ww, int cin, int cin_p, int cout, const char* nm) {
+            memset(&l, 0, sizeof(l));
+            l.kind = 0; l.has_relu = 0; l.is_u8 = 0;
+            l.hin = hh; l.win = ww; l.cin = cin; l.cin_p = cin_p; l.ksz = 3; l.stride = 1; l.taps = 9;
+            int pad_w;
+            same_padding(hh, 3, 1, l.hout, l.pad);
+            same_padding(ww, 3, 1, l.wout, pad_w);
+            l.cout = cout; l.cout_p = round_up(cout, 8);
+            l.npix = l.hout * l.wout;
+            l.out_f = l.cout; l.out_p = l.cout_p;
+            l.K = l.taps * l.cin_p;
+            l.in_elems_p = hh * ww * cin_p;
+            l.out_elems_p = l.npix * l.cout_p;
+            l.w_size = (int64_t)l.cout_p * l.K;
+            snprintf(l.name, sizeof(l.name), "%s", nm);
+            l.w_off = poff; poff += l.w_size;
+            l.b_off = poff; poff += l.out_p;
+            l.g_off = l.be_off = -1;
+        };
+        for (int s = 0; s < IMP_STACKS; ++s) {
+            ImpalaStack& S = P.imp[s];
+            memset(&S, 0, sizeof(S));
+            S.H = h; S.W = w; S.cin = c; S.cin_p = c_p;
+            S.C = cfg->features[s];
+            ISDQN_REQUIRE(S.C >= 1 && S.C <= 64, ISDQN_ERR_UNSUPPORTED, "impala stack widths above 64 channels are not supported");
+            S.C_p = round_up(S.C, 8);
+            int pw;
+            same_padding(h, 3, 2, S.Hp, S.pool_pad);
+            same_padding(w, 3, 2, S.Wp, pw);
+            ISDQN_REQUIRE(pw == S.pool_pad, ISDQN_ERR_UNSUPPORTED, "non-square observations are not supported by the impala torso");
+            // parameters in Flax's order inside a Stack: Conv_0, then per block LayerNorm_b, Conv_{1+2b}, Conv_{2+2b} (dqn.py:17-34)
+            char nm[16];
+            snprintf(nm, sizeof(nm), "Conv_0");
+            conv3(S.conv[0], h, w, c, c_p, S.C, nm);
+            for (int b = 0; b < 2; ++b) {
+                if (cfg->layer_norm) {
+                    S.ln_g[b] = poff; poff += S.C_p;
+                    S.ln_b[b] = poff; poff += S.C_p;
+                } else {
+                    S.ln_g[b] = S.ln_b[b] = -1;
+                }
+                for (int k = 1 + 2 * b; k <= 2 + 2 * b; ++k) {
+                    snprintf(nm, sizeof(nm), "Conv_%d", k);
+                    conv3(S.conv[k], S.Hp, S.Wp, S.C, S.C_p, S.C, nm);
+                }
+            }
+            h = S.Hp; w = S.Wp; c = S.C; c_p = S.C_p;
+        }
+        // the torso as one pseudo-layer: output geometry of a conv layer, the LayerNorm behind the last Stack as its LayerNorm
+        Layer& l = P.L[nl++];
+        memset(&l, 0, sizeof(l));
+        l.kind = 2;
+        l.has_ln = cfg->layer_norm ? 1 : 0;
+        l.has_relu = 1;
+        l.hin = cfg->obs_h; l.win = cfg->obs_w; l.cin = cfg->obs_c; l.cin_p = 8;
+        l.hout = h; l.wout = w; l.cout = c; l.cout_p = c_p; l.npix = h * w;
+        l.out_f = c; l.out_p = c_p;
+        l.in_elems_p = cfg->obs_h * cfg->obs_w * 8;
+        l.out_elems_p = l.npix * c_p;
+        l.w_size = 0; l.w_off = -1; l.b_off = -1;
+        snprintf(l.name, sizeof(l.name), "Impala");
+        if (l.has_ln) {
+            l.g_off = poff; poff += l.out_p;
+            l.be_off = poff; poff += l.out_p;
+            snprintf(l.ln_name, sizeof(l.ln_name), "LayerNorm_%d", n_ln++);
+        } else {
+            l.g_off = l.be_off = -1;
+        }
+        in_elems_p = h * w * c_p;
+        in_f = h * w * c;
+        in_p = in_elems_p;
     } else {
         ISDQN_REQUIRE(cfg->obs_c >= 1, ISDQN_ERR_ARG, "bad observation dim");
         in_f = cfg->obs_c;
         in_p = round_up(in_f, 8);
         in_elems_p = in_p;
     }
-    const int first_dense = cfg->arch == ISDQN_ARCH_CNN ? 3 : 0;
+    const int first_dense = cfg->arch == ISDQN_ARCH_FC ? 0 : 3;
     for (int i = first_dense; i <= cfg->n_features; ++i) {
         ISDQN_REQUIRE(nl < MAX_LAYERS, ISDQN_ERR_ARG, "too many layers");
         Layer& l = P.L[nl++];
@@ -240,7 +331,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
                     if (l.wgi_groups > l.gw_slabs) l.gw_slabs = l.wgi_groups;
                 }
             }
-        } else {
+        } else if (l.kind == 1) {
             int tiles = ceil_div(l.out_p, 128) * ceil_div(l.in_p, 128);
             int ksteps = ceil_div(P.B, 32);
             int s = tiles >= 128 ? 1 : 256 / tiles;
@@ -273,9 +364,41 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
             l.part_rows = P.B * P.L[i + 1].dgi_tiles;
         // conv layer under the first dense layer: the fused dense data-gradient + LN backward emits one partial
         // row per (64-sample tile, pixel)
-        if (l.kind == 0 && i + 1 < nl && P.L[i + 1].kind == 1 && l.cout_p == 64 && ceil_div(P.B, 64) * l.npix > l.part_rows)
+        if (l.kind != 1 && i + 1 < nl && P.L[i + 1].kind == 1 && l.cout_p == 64 && ceil_div(P.B, 64) * l.npix > l.part_rows)
             l.part_rows = ceil_div(P.B, 64) * l.npix;
         l.part_off = region(std::string("part/") + l.name, (int64_t)l.part_rows * 3 * l.out_p);
+    }
+    if (cfg->arch == ISDQN_ARCH_IMPALA) {
+        for (int s = 0; s < IMP_STACKS; ++s) {
+            ImpalaStack& S = P.imp[s];
+            const std::string pre = "imp/s" + std::to_string(s) + "/";
+            const int64_t big = (int64_t)S.H * S.W, small = (int64_t)S.Hp * S.Wp;
+            S.xin_off = region(pre + "xin", P.N2 * big * S.cin_p);
+            S.z0_off = region(pre + "z0", P.N2 * big * S.C_p);
+            S.arg_off = region(pre + "argmax", (P.N2 * small * S.C_p + 3) / 4);
+            for (int k = 0; k < 3; ++k) S.r_off[k] = region(pre + "r" + std::to_string(k), P.N2 * small * S.C_p);
+            for (int b = 0; b < 2; ++b) {
+                S.a1_off[b] = region(pre + "a1_" + std::to_string(b), P.N2 * small * S.C_p);
+                S.a2_off[b] = region(pre + "a2_" + std::to_string(b), P.N2 * small * S.C_p);
+                S.lnpart_off[b] = region(pre + "lnpart" + std::to_string(b), (int64_t)LN_MAX_BLOCKS * 2 * S.C_p);
+            }
+            S.zt_off = region(pre + "zt", P.N2 * small * S.C_p);
+            S.dr_off = region(pre + "dr", P.B * small * S.C_p);
+            S.da_off = region(pre + "da", P.B * std::max(big * S.cin_p, small * S.C_p));
+            S.dzs_off = region(pre + "dzs", P.B * big * S.C_p);
+            S.dz0_off = region(pre + "dz0", P.B * big * S.C_p);
+            for (int k = 0; k < IMP_CONVS; ++k) {
+                Layer& c = S.conv[k];
+                S.bpart_off[k] = region(pre + "bpart" + std::to_string(k), (int64_t)LN_MAX_BLOCKS * S.C_p);
+                int tiles_n = ceil_div(c.K, 64);
+                int ksteps = ceil_div(P.B * c.npix, 32);
+                int sp = 256 / tiles_n;
+                if (sp < 1) sp = 1;
+                if (sp > ksteps) sp = ksteps;
+                c.gw_slabs = sp;
+                c.gw_off = region(pre + "gw" + std::to_string(k), (int64_t)c.gw_slabs * c.w_size);
+            }
+        }
     }
     P.q_off = region("q", (int64_t)P.N2 * P.nha_p);
     P.dout_off = region("dout", (int64_t)P.B * P.nha_p);

@@ -515,7 +515,8 @@ struct ConvFwd {
                         ap[r] = (ch0 + r < g.cout) ? fmaxf(y, 0.f) : 0.f;
                         zp[r] = zv[mt][r];
                     }
-                    s8_store_quad_paired(act + (int64_t)pix * g.cout_p, ch0, a.x, a.y, a.z, a.w);
+                    if (act != nullptr)  // (wave-uniform; the impala torso takes some outputs as fp32 `z` only)
+                        s8_store_quad_paired(act + (int64_t)pix * g.cout_p, ch0, a.x, a.y, a.z, a.w);
                     if (pix < z_pix) *reinterpret_cast<float4*>(z + (int64_t)pix * g.cout_p + ch0) = zq;
                 }
             }

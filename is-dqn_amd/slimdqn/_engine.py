@@ -45,12 +45,15 @@ class QNetEngine:
         if architecture_type == "cnn":
             cfg.arch = _hip.ARCH_CNN
             cfg.obs_h, cfg.obs_w, cfg.obs_c = (int(d) for d in observation_dim)
+        elif architecture_type == "impala":  # architectures/dqn.py:7-36, 75-88: three Stacks on the generic engine (csrc/impala.h)
+            cfg.arch = _hip.ARCH_IMPALA
+            cfg.obs_h, cfg.obs_w, cfg.obs_c = (int(d) for d in observation_dim)
         elif architecture_type == "fc":
             cfg.arch = _hip.ARCH_FC
             cfg.obs_h = cfg.obs_w = 1
             cfg.obs_c = int(np.prod(observation_dim))
         else:
-            raise NotImplementedError(f"architecture_type={architecture_type!r}: only 'cnn' and 'fc' are on the hot path")
+            raise NotImplementedError(f"architecture_type={architecture_type!r}: 'cnn', 'impala' or 'fc'")
         feats = [int(f) for f in features]
         if len(feats) > _hip.MAX_FEATURES:
             raise ValueError("too many features")
@@ -102,7 +105,8 @@ class QNetEngine:
 
     # ------------------------------------------------------------------ parameter layout
     def _first_dense_after_conv(self, info) -> bool:
-        return self.architecture_type == "cnn" and info.kind == 1 and info.layer == 3
+        # (the first Dense behind the torso: layer 3 of the cnn plan, layer 1 behind the impala pseudo-layer)
+        return info.kind == 1 and ((self.architecture_type == "cnn" and info.layer == 3) or (self.architecture_type == "impala" and info.layer == 1))
 
     def _to_internal(self, info, arr: np.ndarray) -> np.ndarray:
         arr = np.asarray(arr, dtype=np.float32)
@@ -160,7 +164,7 @@ class QNetEngine:
         """Load a reference-layout pytree ({"Conv_0": {"kernel": HWIO, "bias"}, "LayerNorm_0": ...})."""
         flat = np.zeros(self.n_param_floats, np.float32)
         for info in self.infos:
-            mod, leaf = info.name.decode().split("/")
+            mod, leaf = info.name.decode().rsplit("/", 1)  # (impala: "Stack_0/Conv_1" / "kernel")
             v = self._to_internal(info, params[mod][leaf])
             assert v.size == info.size, (info.name, v.size, info.size)
             flat[info.offset : info.offset + info.size] = v
@@ -170,7 +174,7 @@ class QNetEngine:
         flat = (self.params if source is None else source).detach().cpu().numpy()
         out: Dict[str, Dict[str, np.ndarray]] = {}
         for info in self.infos:
-            mod, leaf = info.name.decode().split("/")
+            mod, leaf = info.name.decode().rsplit("/", 1)  # (impala: "Stack_0/Conv_1" / "kernel")
             out.setdefault(mod, {})[leaf] = self._from_internal(info, flat[info.offset : info.offset + info.size])
         return out
 
@@ -180,7 +184,7 @@ class QNetEngine:
         rng = np.random.default_rng(seed)
         params: Dict[str, Dict[str, np.ndarray]] = {}
         for info in self.infos:
-            mod, leaf = info.name.decode().split("/")
+            mod, leaf = info.name.decode().rsplit("/", 1)  # (impala: "Stack_0/Conv_1" / "kernel")
             shape = tuple(info.flax_shape[: info.ndim])
             if info.kind in (0, 1):
                 if info.kind == 0:
@@ -188,7 +192,8 @@ class QNetEngine:
                     fan_in, fan_out = rf * shape[2], rf * shape[3]
                 else:
                     fan_in, fan_out = shape
-                if self.architecture_type == "cnn":
+                xavier = self.architecture_type == "cnn" or (self.architecture_type == "impala" and (info.kind == 1 or mod.endswith("/Conv_0")))
+                if xavier:  # (impala: kernel_init is passed to each Stack's first conv and to the Dense layers only, dqn.py:17-21, 96)
                     lim = math.sqrt(6.0 / (fan_in + fan_out))
                     w = rng.uniform(-lim, lim, size=shape)
                 else:

@@ -19,7 +19,7 @@ ERR_CAPACITY, ERR_NEGATIVE, ERR_SHAPE, ERR_EMPTY, ERR_RANGE, ERR_UNSUPPORTED, ER
 STATUS_NEGATIVE_VALUE, STATUS_TARGET_RANGE, STATUS_EMPTY_TREE = 1, 2, 4
 BATCH_MIRROR_CURRENT = 1  # include/isdqn_hip.h: ISDQN_BATCH_MIRROR_CURRENT
 TREE_MAX_BATCH = 4096
-ARCH_CNN, ARCH_FC = 0, 1
+ARCH_CNN, ARCH_FC, ARCH_IMPALA = 0, 1, 2
 PRECISION_BF16X3, PRECISION_BF16 = 0, 1
 MAX_FEATURES = 8
 

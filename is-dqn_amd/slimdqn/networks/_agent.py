@@ -17,7 +17,15 @@ class DeviceParams:
         self.tensor = tensor
 
     def to_flax(self):
-        return self._engine.export_flax(self.tensor)
+        """The reference's ``params["params"]`` pytree; nested modules (the impala Stacks) as nested dicts like Flax's."""
+        flat = self._engine.export_flax(self.tensor)
+        out = {}
+        for mod, leaves in flat.items():
+            node = out
+            for part in mod.split("/"):
+                node = node.setdefault(part, {})
+            node.update(leaves)
+        return out
 
     def __getitem__(self, key):
         if key != "params":
@@ -101,6 +109,9 @@ class EngineAgent:
         if isinstance(params, DeviceParams):
             return params.tensor
         tree = params["params"] if "params" in params else params
+        if any(k.startswith("Stack_") and "/" not in k for k in tree):  # Flax nesting -> the engine's flattened "Stack_0/Conv_1" keys
+            tree = {**{f"{k}/{m}": v for k, sub in tree.items() if k.startswith("Stack_") for m, v in sub.items()},
+                    **{k: v for k, v in tree.items() if not k.startswith("Stack_")}}
         t = torch.empty_like(self._engine.params)
         self._engine.import_flax(tree, target=t)
         return t

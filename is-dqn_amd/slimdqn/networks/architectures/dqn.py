@@ -5,7 +5,9 @@
   * "cnn": Conv 8x8/4 -> Conv 4x4/2 -> Conv 3x3/1, each SAME-padded, + LayerNorm(channels) + ReLU,
            flatten (h, w, c), then Dense -> LayerNorm -> ReLU per remaining feature, final Dense  (:48-74, :93-103)
   * "fc":  Dense -> LayerNorm -> ReLU per feature, final Dense                                      (:89-103)
-  * "impala" and BatchNorm variants are outside the hot-path scope and raise.
+  * "impala": three Stacks (Conv 3x3 -> max_pool 3x3/2 SAME -> two residual blocks [LayerNorm] -> ReLU -> Conv -> ReLU -> Conv -> +),
+           [LayerNorm] -> ReLU -> flatten, then the same Dense tail                                  (:7-36, :75-88; csrc/impala.h)
+  * BatchNorm variants are not built and raise.
 """
 from typing import Sequence
 
@@ -13,11 +15,11 @@ from typing import Sequence
 class DQNNet:
     def __init__(self, features: Sequence[int], architecture_type: str, final_feature: int, layer_norm: bool = False,
                  batch_norm: bool = False):
-        if architecture_type not in ("cnn", "fc"):
-            raise NotImplementedError(f"architecture_type={architecture_type!r} is outside the hot-path scope")
+        if architecture_type not in ("cnn", "impala", "fc"):
+            raise NotImplementedError(f"architecture_type={architecture_type!r}: 'cnn', 'impala' or 'fc'")
         if batch_norm:
             raise NotImplementedError("batch_norm is outside the hot-path scope")
-        if architecture_type == "cnn" and len(features) < 3:
+        if architecture_type in ("cnn", "impala") and len(features) < 3:
             raise ValueError("cnn needs at least the three convolution widths")
         self.features = [int(f) for f in features]
         self.architecture_type = architecture_type

@@ -54,7 +54,7 @@ class iSDQN:
         self.features = [int(f) for f in features]
         self.architecture_type = architecture_type
         self.layer_norm = layer_norm
-        self.last_idx_mlp = len(features) if architecture_type == "fc" else len(features) - 3
+        self.last_idx_mlp = len(features) if architecture_type == "fc" else len(features) - 3  # (cnn and impala: isdqn.py:33)
         self.final_feature = (1 + n_bellman_iterations) * n_actions
         self.dtype = dtype
         if params is None:

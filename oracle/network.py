@@ -135,6 +135,26 @@ def init_params(
         width = h * w * c
         dense_feats = [int(f) for f in features[3:]]
         init = lambda shape: xavier(shape, shape[0], shape[1])
+    elif architecture_type == "impala":
+        # dqn.py:75-88 + Stack (dqn.py:7-36): three stacks of conv3x3 -> max_pool 3x3 / 2 SAME -> two residual blocks
+        # ([LayerNorm] -> relu -> conv3x3 -> relu -> conv3x3 -> + input); modules are auto-named per class INSIDE each Stack
+        # (Conv_0 .. Conv_4, LayerNorm_0 .. LayerNorm_1), the Stacks Stack_0 .. Stack_2, and the LayerNorm behind the last stack
+        # is the top level's LayerNorm_0.  The stack's first conv takes xavier_uniform, the block convs Flax's default
+        # lecun_normal (dqn.py:17-21 passes kernel_init only there).  Nested modules are flattened to "Stack_s/Conv_k" keys.
+        h, w, c = observation_dim
+        for s_idx in range(3):
+            cout = int(features[s_idx])
+            params[f"Stack_{s_idx}/Conv_0"] = {"kernel": xavier((3, 3, c, cout), 9 * c, 9 * cout), "bias": np.zeros(cout, np.float32)}
+            for b in range(2):
+                if layer_norm:
+                    params[f"Stack_{s_idx}/LayerNorm_{b}"] = {"scale": np.ones(cout, np.float32), "bias": np.zeros(cout, np.float32)}
+                for k in (1 + 2 * b, 2 + 2 * b):
+                    params[f"Stack_{s_idx}/Conv_{k}"] = {"kernel": lecun((3, 3, cout, cout), 9 * cout), "bias": np.zeros(cout, np.float32)}
+            h, w, c = same_padding(h, 3, 2)[0], same_padding(w, 3, 2)[0], cout
+        add_ln(c)
+        width = h * w * c
+        dense_feats = [int(f) for f in features[3:]]
+        init = lambda shape: xavier(shape, shape[0], shape[1])
     elif architecture_type == "fc":
         width = int(np.prod(observation_dim))
         dense_feats = [int(f) for f in features]
@@ -173,6 +193,36 @@ def _conv_same(x_nhwc: torch.Tensor, kernel_hwio: torch.Tensor, bias: torch.Tens
     return y.permute(0, 2, 3, 1)
 
 
+def _max_pool_same(x_nhwc: torch.Tensor, window: int = 3, stride: int = 2) -> torch.Tensor:
+    """flax.linen.max_pool(x, (3, 3), strides=(2, 2), padding="SAME") (dqn.py:22): -inf padding, lo = total // 2."""
+    _, plo_h, phi_h = same_padding(x_nhwc.shape[1], window, stride)
+    _, plo_w, phi_w = same_padding(x_nhwc.shape[2], window, stride)
+    x = F.pad(x_nhwc.permute(0, 3, 1, 2), (plo_w, phi_w, plo_h, phi_h), value=float("-inf"))
+    return F.max_pool2d(x, window, stride).permute(0, 2, 3, 1)
+
+
+def _impala_stack(params, prefix: str, x: torch.Tensor, layer_norm: bool, capture: dict | None = None) -> torch.Tensor:
+    """Stack.__call__ (dqn.py:14-36) without BatchNorm.  ``capture`` receives the residual stream in front of each block."""
+    p = params[f"{prefix}/Conv_0"]
+    x = _conv_same(x, p["kernel"], p["bias"], 1)
+    x = _max_pool_same(x)
+    for b in range(2):
+        block_input = x
+        if capture is not None:
+            capture[f"{prefix}/r{b}"] = x
+        if layer_norm:
+            q = params[f"{prefix}/LayerNorm_{b}"]
+            x = _layer_norm(x, q["scale"], q["bias"])
+        x = torch.relu(x)
+        p = params[f"{prefix}/Conv_{1 + 2 * b}"]
+        x = _conv_same(x, p["kernel"], p["bias"], 1)
+        x = torch.relu(x)
+        p = params[f"{prefix}/Conv_{2 + 2 * b}"]
+        x = _conv_same(x, p["kernel"], p["bias"], 1)
+        x = x + block_input
+    return x
+
+
 def forward(params, x, features, architecture_type: str, layer_norm: bool, capture: dict | None = None):
     """DQNNet.__call__ (dqn.py:47-103) for a batch.  ``params``: dict of dicts of torch tensors.
 
@@ -196,6 +246,18 @@ def forward(params, x, features, architecture_type: str, layer_norm: bool, captu
             if capture is not None:
                 capture[f"Conv_{i}"] = x
         x = x.reshape(x.shape[0], -1)
+        start = 3
+    elif architecture_type == "impala":  # dqn.py:75-88
+        x = x / 255.0
+        for s_idx in range(3):
+            x = _impala_stack(params, f"Stack_{s_idx}", x, layer_norm, capture)
+            if capture is not None:
+                capture[f"Stack_{s_idx}"] = x
+        if layer_norm:
+            q = params[f"LayerNorm_{n_ln}"]
+            x = _layer_norm(x, q["scale"], q["bias"])
+            n_ln += 1
+        x = torch.relu(x).reshape(x.shape[0], -1)
         start = 3
     else:
         x = x.reshape(x.shape[0], -1)
