@@ -124,3 +124,66 @@ def test_fc_architecture_runs():
                       next_state=rng.normal(size=(5, 8)), is_terminal=rng.integers(0, 2, 5))
     p, st, losses = ag.learn_on_batch(ag.params, ag.optimizer_state, s)
     assert losses.shape == (1,) and np.isfinite(losses).all()
+
+
+def test_impala_torso_restatement_against_plain_numpy_loops():
+    """Stack (architectures/dqn.py:7-36): conv3x3 SAME, max_pool 3x3/2 SAME (-inf padding, pad_lo = total // 2), two residual blocks
+    [LayerNorm] -> relu -> conv -> relu -> conv -> + input; torso :75-88.  torch statement vs loops in float64 on a small input."""
+    import numpy as np
+    import torch
+
+    from oracle import network as net
+
+    feats, obs, final = [3, 4, 2, 5], (13, 13, 2), 6
+    params = net.init_params(1, obs, feats, "impala", final, True)
+    rng = np.random.default_rng(0)
+    for m in params:
+        for n in params[m]:
+            if n != "kernel":
+                params[m][n] = (params[m][n] + rng.normal(0, 0.2, params[m][n].shape)).astype(np.float32)
+    x = rng.integers(0, 256, (2,) + obs).astype(np.uint8)
+    got = net.forward(net.to_torch(params, torch.float64), torch.tensor(x), feats, "impala", True).numpy()
+
+    P = {m: {n: np.asarray(a, np.float64) for n, a in l.items()} for m, l in params.items()}
+
+    def conv(t, p):
+        N, H, W, C = t.shape
+        tp = np.zeros((N, H + 2, W + 2, C))
+        tp[:, 1:-1, 1:-1] = t
+        out = np.zeros((N, H, W, p["kernel"].shape[3]))
+        for y in range(H):
+            for xx in range(W):
+                out[:, y, xx] = np.tensordot(tp[:, y : y + 3, xx : xx + 3], p["kernel"], axes=([1, 2, 3], [0, 1, 2])) + p["bias"]
+        return out
+
+    def pool(t):
+        N, H, W, C = t.shape
+        Ho, Wo = -(-H // 2), -(-W // 2)
+        lo_h, lo_w = max((Ho - 1) * 2 + 3 - H, 0) // 2, max((Wo - 1) * 2 + 3 - W, 0) // 2
+        out = np.full((N, Ho, Wo, C), -np.inf)
+        for oy in range(Ho):
+            for ox in range(Wo):
+                for ky in range(3):
+                    for kx in range(3):
+                        iy, ix = 2 * oy - lo_h + ky, 2 * ox - lo_w + kx
+                        if 0 <= iy < H and 0 <= ix < W:
+                            out[:, oy, ox] = np.maximum(out[:, oy, ox], t[:, iy, ix])
+        return out
+
+    def ln(z, q):
+        mean = z.mean(-1, keepdims=True)
+        var = np.maximum((z * z).mean(-1, keepdims=True) - mean * mean, 0.0)
+        return (z - mean) / np.sqrt(var + 1e-6) * q["scale"] + q["bias"]
+
+    t = x.astype(np.float64) / 255.0
+    for s in range(3):
+        t = pool(conv(t, P[f"Stack_{s}/Conv_0"]))
+        for b in range(2):
+            r = t
+            t = np.maximum(ln(t, P[f"Stack_{s}/LayerNorm_{b}"]), 0.0)
+            t = np.maximum(conv(t, P[f"Stack_{s}/Conv_{1 + 2 * b}"]), 0.0)
+            t = conv(t, P[f"Stack_{s}/Conv_{2 + 2 * b}"]) + r
+    t = np.maximum(ln(t, P["LayerNorm_0"]), 0.0).reshape(2, -1)
+    t = np.maximum(ln(t @ P["Dense_0"]["kernel"] + P["Dense_0"]["bias"], P["LayerNorm_1"]), 0.0)
+    want = t @ P["Dense_1"]["kernel"] + P["Dense_1"]["bias"]
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10)
