@@ -34,7 +34,7 @@ extern "C" {
 #define ISDQN_ERR_SHAPE (-3)       /* sum_tree.py:30  indices/values shape mismatch              -> AssertionError */
 #define ISDQN_ERR_EMPTY (-4)       /* replay_buffer.py:200 / samplers.py:41 empty buffer         -> AssertionError */
 #define ISDQN_ERR_RANGE (-5)       /* sum_tree.py:73-74 target outside [0, root)                 -> ValueError     */
-#define ISDQN_ERR_UNSUPPORTED (-6) /* configuration outside the hot-path scope (impala, BatchNorm, ...) */
+#define ISDQN_ERR_UNSUPPORTED (-6) /* configuration that is not built (BatchNorm, conv widths above 64 channels, ...) */
 #define ISDQN_ERR_HIP (-7)         /* a HIP runtime call failed; see isdqn_last_error()           */
 #define ISDQN_ERR_ARG (-8)         /* null pointer / bad size                                     */
 

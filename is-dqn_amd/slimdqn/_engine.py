@@ -367,14 +367,26 @@ class QNetEngine:
     # told that it is current.  learn_on_batch leaves it current; any torch-side in-place write to `self.params` bumps the
     # tensor's version counter, a head shift goes through `shift_params` -- both invalidate.
     def _mirror_is_current(self, params) -> bool:
-        return params is None and getattr(self, "_mirror_version", None) == self.params._version
+        """Trust rule: the mirror is reused only when (a) the call reads the engine's own buffer, (b) the last call
+        of THIS engine left the mirror equal to it, (c) no torch operation has written the tensor since (version counter) and (d) the
+        tensor object and its storage are the ones the engine allocated (a rebound ``eng.params`` / ``.data`` is not trusted).  What
+        the counter cannot see -- a raw-pointer write from outside this class -- must call ``invalidate_mirror()``; every write this
+        package makes goes through torch ops or through the library calls below."""
+        return (params is None and getattr(self, "_mirror_version", None) == self.params._version
+                and self.params.data_ptr() == getattr(self, "_mirror_ptr", None))
+
+    def invalidate_mirror(self) -> None:
+        """Force the next call to rebuild the weight mirror from ``params`` (for writers that bypass torch's version counter)."""
+        self._mirror_version = None
 
     def _mirror_made_current(self) -> None:
         self._mirror_version = self.params._version
+        self._mirror_ptr = self.params.data_ptr()
 
     def _mirror_holds(self, params) -> None:
         """The call just enqueued rebuilt the mirror from `params` (None = the engine's own buffer)."""
         self._mirror_version = self.params._version if params is None else None
+        self._mirror_ptr = self.params.data_ptr()
 
     def best_actions(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, idx_networks: torch.Tensor, params=None,
                      out: torch.Tensor | None = None, mirror_current: bool | None = None) -> torch.Tensor:
