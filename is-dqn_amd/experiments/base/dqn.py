@@ -84,7 +84,9 @@ def train(key, p: dict, agent, env, rb):
             if vector:
                 # (collects the round started by the previous call, starts the next one, returns: the gradient steps below
                 # are enqueued while the emulators run)
-                round_results = collect_vector_samples(rng, env, agent, rb, p, epsilon_schedule, n_training_steps)
+                first_step = n_training_steps
+                round_results = collect_vector_samples(rng, env, agent, rb, p, epsilon_schedule, n_training_steps,
+                                                       between=lambda res: after_round(first_step, len(res)))
                 for i, (reward, ended) in enumerate(round_results):
                     run_return[i] += reward
                     run_length[i] += 1
@@ -93,7 +95,6 @@ def train(key, p: dict, agent, env, rb):
                         lengths[idx_epoch].append(run_length[i])
                         run_return[i], run_length[i] = 0.0, 0
                         has_reset = True
-                after_round(n_training_steps, len(round_results))
                 steps_in_epoch += len(round_results)
                 n_training_steps += len(round_results)
                 continue

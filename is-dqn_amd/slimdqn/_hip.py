@@ -234,12 +234,26 @@ def resolve_device(device):
     return dev
 
 
+_CUDA_OK = None
+
+
+def _cuda_ok() -> bool:
+    """torch.cuda.is_available(), asked once: it is a driver call (~80 us), and the per-call device binding below sits on the
+    acting / update path."""
+    global _CUDA_OK
+    if _CUDA_OK is None:
+        import torch
+
+        _CUDA_OK = bool(torch.cuda.is_available())
+    return _CUDA_OK
+
+
 def bind_device(device) -> None:
     """Make `device` the calling thread's current HIP device: the library launches on the current device (per-device
     side stream, function attributes), so an object on cuda:k must only ever be driven with cuda:k current."""
     import torch
 
-    if device.type == "cuda" and torch.cuda.is_available() and torch.cuda.current_device() != device.index:
+    if device.type == "cuda" and _cuda_ok() and torch.cuda.current_device() != device.index:
         torch.cuda.set_device(device)
 
 

@@ -264,7 +264,7 @@ class EngineAgent:
         out = eng.best_actions(idx_networks=idx, params=self._bind(params), **self._states_to_device(states))
         return out.cpu().numpy()
 
-    def _best_actions_planes(self, params, planes: np.ndarray, rows: np.ndarray, idx_networks) -> np.ndarray:
+    def _best_actions_planes(self, params, planes: np.ndarray, rows: np.ndarray, idx_networks, wait: bool = True):
         """Greedy actions of the environments ``rows`` of a VectorEnv: ``planes`` is its host block uint8 [n][stack][h*w]
         (planar stacks, oldest .. newest; pinned when the runtime registered the mapping).  ONE host-to-device copy of the
         block, one small copy of (plane ids, head indices), one forward over len(rows) observations, one read-back."""
@@ -289,12 +289,18 @@ class EngineAgent:
         eng.best_actions(frames=v["dev"], frame_stride=hw, frame_ids=v["small"][: m * stack], idx_networks=v["small"][n * stack : n * stack + m],
                          params=self._bind(params), out=v["out"][:m])
         v["host_out"][:m].copy_(v["out"][:m], non_blocking=True)
-        torch.cuda.current_stream(eng.device).synchronize()
-        return v["host_out"][:m].numpy().astype(np.int64)
+        ev = v.setdefault("event", torch.cuda.Event())
+        ev.record(torch.cuda.current_stream(eng.device))
+
+        def result() -> np.ndarray:
+            ev.synchronize()  # (this forward only: work enqueued behind it -- the round's gradient steps -- keeps running)
+            return v["host_out"][:m].numpy().astype(np.int64)
+
+        return result() if wait else result
 
     # generic forms (one head, per-step replays); iSDQN overrides both
-    def best_actions_planes(self, params, planes, rows, key=None) -> np.ndarray:
-        return self._best_actions_planes(params, planes, rows, np.zeros(len(rows), dtype=np.int32))
+    def best_actions_planes(self, params, planes, rows, key=None, wait: bool = True):
+        return self._best_actions_planes(params, planes, rows, np.zeros(len(rows), dtype=np.int32), wait=wait)
 
     def learn_steps(self, n_steps: int, replay_buffer) -> None:
         for _ in range(n_steps):

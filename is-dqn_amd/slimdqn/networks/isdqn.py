@@ -178,8 +178,9 @@ class iSDQN(EngineAgent):
             idx = int(key.integers(0, self.n_bellman_iterations))
         return self._best_action(params, state, idx)
 
-    def best_actions_planes(self, params, planes, rows, key=None) -> np.ndarray:
-        """``best_actions`` on the planar host block of a VectorEnv (environments/vector.py) for its environments ``rows``."""
+    def best_actions_planes(self, params, planes, rows, key=None, wait: bool = True):
+        """``best_actions`` on the planar host block of a VectorEnv (environments/vector.py) for its environments ``rows``.
+        ``wait=False`` returns a function that waits for THIS forward and returns the actions (the caller enqueues more work first)."""
         n = len(rows)
         if key is None:
             idx = self._action_rng.integers(0, self.n_bellman_iterations, size=n)
@@ -187,7 +188,7 @@ class iSDQN(EngineAgent):
             idx = key.integers(0, self.n_bellman_iterations, size=n)
         else:
             idx = np.broadcast_to(np.asarray(key), (n,))
-        return self._best_actions_planes(params, planes, rows, idx)
+        return self._best_actions_planes(params, planes, rows, idx, wait=wait)
 
     def best_actions(self, params, states, key=None) -> np.ndarray:
         """``best_action`` for n observations (vectorised host environments): one head draw per observation from ``key``

@@ -45,7 +45,7 @@ def collect_single_sample(key, env, agent, rb: ReplayBuffer, p, epsilon_schedule
     return reward, episode_end
 
 
-def collect_vector_samples(key, venv, agent, rb: ReplayBuffer, p, epsilon_schedule, n_training_steps: int):
+def collect_vector_samples(key, venv, agent, rb: ReplayBuffer, p, epsilon_schedule, n_training_steps: int, between=None):
     """One round of ``collect_single_sample`` (utils.py:21-43) over the n environments of a VectorEnv, pipelined:
 
       1. the environment steps started by the PREVIOUS call are collected (``step_wait``) and their n transitions enter the
@@ -53,8 +53,11 @@ def collect_vector_samples(key, venv, agent, rb: ReplayBuffer, p, epsilon_schedu
       2. the next actions are chosen from the environments' current frame stacks -- epsilon draws per environment as in
          ``select_action`` (environment i of the round uses the schedule at step n_training_steps + results + i, which is what
          n consecutive ``collect_single_sample`` calls would use), ONE batched forward and one read-back for the greedy ones;
-      3. ``step_async`` starts the next round and the call returns, so the caller enqueues the round's gradient steps while the
-         emulators run (with worker processes: in parallel on the host cores, under the update kernels).
+      3. ``between(results)`` (the trainer: the cadence of the collected round -- its gradient steps as one graph replay) runs
+         while the acting forward is in flight, BEFORE its actions are waited for: the GPU always has the next replay queued
+         behind the forward instead of idling through the host's flush / draw / launch work;
+      4. ``step_async`` starts the next round and the call returns: the emulators run under the update kernels (with worker
+         processes: in parallel on the host cores).
 
     Returns [(reward, episode_end)] of the collected round in environment order -- empty on the very first call.
     Image observations only (the stacks travel as uint8 planes); an fc agent keeps ``collect_single_sample``."""
@@ -80,9 +83,14 @@ def collect_vector_samples(key, venv, agent, rb: ReplayBuffer, p, epsilon_schedu
     n_explore = int(explore.sum())
     if n_explore:
         actions[explore] = key.integers(0, venv.n_actions, size=n_explore)
+    pending = None
     if n_explore < n:
         greedy = np.flatnonzero(~explore)
-        actions[greedy] = agent.best_actions_planes(agent.params, venv.planes, greedy, key=key)
+        pending = agent.best_actions_planes(agent.params, venv.planes, greedy, key=key, wait=False)
+    if between is not None:
+        between(out)
+    if pending is not None:
+        actions[greedy] = pending()
     venv._last_actions = actions
     venv.step_async(actions)
     return out
