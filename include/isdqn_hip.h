@@ -156,6 +156,16 @@ typedef struct isdqn_net_config {
     float huber_delta;                    /* 0: squared TD error, the reference's loss (isdqn.py:102); > 0: Huber loss with
                                            * this delta (0.5 d^2 for |d| <= delta, delta (|d| - delta/2) beyond; the north
                                            * star's wording), gradient clip(d, -delta, delta)                */
+    int32_t batch_norm;                   /* 0/1 (dqn.py:52-53, 59-60, 66-67, 73-74, 100-101): flax.linen.BatchNorm behind the
+                                           * input scaling and behind every hidden layer's ReLU -- `axis=(1, 2)` on image
+                                           * tensors (statistics per pixel position over batch AND channels), per feature on
+                                           * flattened / dense activations; momentum 0.99, epsilon 1e-5.  learn / loss run it on
+                                           * the batch statistics of concat(state, next_state) (isdqn.py:95), which couples the two
+                                           * halves: the backward then runs over all 2B rows (csrc/batchnorm.h, generic engine,
+                                           * one stream).  forward / best_action(s) use the running averages (isdqn.py:130).
+                                           * cnn and fc only; the *_target (DQN) and grad_on_batch / analysis entry points
+                                           * return ISDQN_ERR_UNSUPPORTED with it (the reference's DQN cannot run with it either:
+                                           * dqn.py:86 applies the network without a mutable batch_stats collection).          */
 } isdqn_net_config;
 
 /* One parameter tensor inside the flat fp32 parameter buffer.  `name` is the Flax
@@ -169,7 +179,10 @@ typedef struct isdqn_tensor_info {
     char name[48];
     int64_t offset; /* in floats */
     int64_t size;   /* in floats, internal (padded) */
-    int32_t kind;   /* 0 conv kernel, 1 dense kernel, 2 bias, 3 ln scale, 4 ln bias */
+    int32_t kind;   /* 0 conv kernel, 1 dense kernel, 2 bias, 3 ln scale, 4 ln bias; BatchNorm_i: 5 scale, 6 bias ("params"
+                     * collection), 7 mean, 8 var ("batch_stats" collection: running averages, not touched by Adam).
+                     * BatchNorm tensors: dims = [groups, P, C, C padded to 8]; spatial sites (flax_shape (H, W)) hold one
+                     * value per pixel position, feature sites (flax_shape (P*C,)) one per internal column p*Cpad + c */
     int32_t layer;  /* index into the layer list */
     int32_t ndim;
     int32_t flax_shape[4];

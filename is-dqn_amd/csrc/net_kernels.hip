@@ -1200,6 +1200,7 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const floa
                                 ip.plane_elems, ip.PP);
     constexpr int LDS_LIMIT = 158 * 1024;  // of the 160 KB, minus the kernels' static arrays
     if (lds > LDS_LIMIT || (l.is_u8 && (l.win < 8 || l.cin > 4))) return ISDQN_OK;  // (frame ids of a stack live in 4 registers)
+    if (!l.is_u8 && l.cin_p < 16) return ISDQN_OK;  // (8-channel S8 inputs -- the BatchNorm networks' first convolution -- take the generic engine)
     // A row pitch of wout (mod 8) pixels keeps the bank pattern of a fragment's pixel columns going across the end of an
     // image row (conv_img.h, PixelOrder: the short last strip of every row is where the conflicts are left); taken when it
     // costs no workgroup per CU (11-pixel rows of the stride-2 layer: 24 -> 27 columns, conflict factor 1.75 -> 1.0).
@@ -1400,9 +1401,16 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const float* 
 static int impala_forward(const Plan& P, bool x3, const float* params, const float* wmir, const NetInput& in, int n_img, int z_img,
                           float* ws, hipStream_t st);  // impala.h
 
+static int bn_forward(const Plan& P, bool x3, const float* params, const NetInput& in, int n_img, int z_img, float* ws, float* q_out, bool running,
+                      hipStream_t st);  // batchnorm.h
+
 // forward over n_img images; hidden activations -> ws act regions, head output -> q_out [n_img][nha_p]
 static int net_forward(const Plan& P, bool x3, const float* params, const NetInput& in, int n_img, int z_img,
                        float* ws, float* q_out, hipStream_t st, int n_run = -1, int skip_post_layer = -1) {
+    if (P.bn) {  // BatchNorm networks outside a learn step: the running averages (isdqn.py:130, use_running_average=True)
+        ISDQN_REQUIRE(n_run < 0 && skip_post_layer < 0, ISDQN_ERR_UNSUPPORTED, "partial forward passes are not built for BatchNorm networks");
+        return bn_forward(P, x3, params, in, n_img, z_img, ws, q_out, true, st);
+    }
     const float* prev = nullptr;
     const float* wmir = ws + P.wsplit_off;  // refreshed by the caller (refresh_mirror) from `params`
     if (n_run < 0) n_run = P.n_layers;
@@ -1686,6 +1694,7 @@ static int conv_wgrad_slabs(const Layer& l, int n_img) {
 }
 
 #include "impala.h"
+#include "batchnorm.h"
 
 }  // namespace isdqn
 
@@ -1702,14 +1711,14 @@ extern "C" int isdqn_net_param_layout(const isdqn_net_config* cfg, int64_t* n_pa
     if (n_param_floats) *n_param_floats = P.n_params;
     int n = 0;
     auto add = [&](const char* mod, const char* leaf, int64_t off, int64_t size, int kind, int layer, int ndim,
-                   int s0, int s1, int s2, int s3, int d0, int d1, int d2) {
+                   int s0, int s1, int s2, int s3, int d0, int d1, int d2, int d3 = 0) {
         if (infos && n < max_infos) {
             isdqn_tensor_info& t = infos[n];
             memset(&t, 0, sizeof(t));
             snprintf(t.name, sizeof(t.name), "%s/%s", mod, leaf);
             t.offset = off; t.size = size; t.kind = kind; t.layer = layer; t.ndim = ndim;
             t.flax_shape[0] = s0; t.flax_shape[1] = s1; t.flax_shape[2] = s2; t.flax_shape[3] = s3;
-            t.dims[0] = d0; t.dims[1] = d1; t.dims[2] = d2; t.dims[3] = 0;
+            t.dims[0] = d0; t.dims[1] = d1; t.dims[2] = d2; t.dims[3] = d3;
         }
         ++n;
     };
@@ -1748,6 +1757,16 @@ extern "C" int isdqn_net_param_layout(const isdqn_net_config* cfg, int64_t* n_pa
         if (l.has_ln) {
             add(l.ln_name, "scale", l.g_off, l.out_p, 3, i, 1, l.out_f, 0, 0, 0, l.out_p, 0, 0);
             add(l.ln_name, "bias", l.be_off, l.out_p, 4, i, 1, l.out_f, 0, 0, 0, l.out_p, 0, 0);
+        }
+    }
+    for (int s = 0; s < P.n_bn; ++s) {  // BatchNorm_s: scale / bias ("params"), mean / var ("batch_stats")
+        const BnSite& b = P.bns[s];
+        const int H = b.layer < 0 ? P.L[0].hin : P.L[b.layer].hout, W = b.layer < 0 ? P.L[0].win : P.L[b.layer].wout;
+        const int64_t offs[4] = {b.scale_off, b.bias_off, b.mean_off, b.var_off};
+        static const char* const leaves[4] = {"scale", "bias", "mean", "var"};
+        for (int k = 0; k < 4; ++k) {
+            if (b.spatial) add(b.name, leaves[k], offs[k], b.G_p, 5 + k, b.layer, 2, H, W, 0, 0, b.G, b.P, b.C, b.Cp);
+            else add(b.name, leaves[k], offs[k], b.G_p, 5 + k, b.layer, 1, b.P * b.C, 0, 0, 0, b.G, b.P, b.C, b.Cp);
         }
     }
     if (n_infos) *n_infos = n;
@@ -1878,6 +1897,12 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         // those (unused) loads read the parameters instead of a null pointer
         adam_m = params;
         adam_v = params;
+    }
+    if (P.bn) {  // BatchNorm: the layer-by-layer form over all 2B rows (batchnorm.h)
+        ISDQN_REQUIRE(target_params == nullptr && sel == nullptr && (!learn || update), ISDQN_ERR_UNSUPPORTED,
+                      "BatchNorm networks: learn_on_batch / loss_on_batch only (the reference's DQN cannot run with batch_norm either, dqn.py:86)");
+        return bn_learn_or_loss(cfg, P, params, adam_m, adam_v, adam_count, batch, losses, loss_accum, q_values, targets, priorities,
+                                (float*)workspace, (hipStream_t)stream, learn, grad_out, update);
     }
     const bool x3 = cfg->precision == ISDQN_PRECISION_BF16X3;
     const int B = P.B, K = sel ? sel->K : P.K;

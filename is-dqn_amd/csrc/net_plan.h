@@ -61,11 +61,30 @@ struct ImpalaStack {
     int64_t dr_off, da_off, dzs_off, dz0_off, bpart_off[IMP_CONVS], lnpart_off[2];
 };
 
+// One flax.linen.BatchNorm call site (architectures/dqn.py:52-53, 59-60, 66-67, 73-74, 100-101; csrc/batchnorm.h).  The tensor it
+// normalises is [rows][P][Cp] in the internal layout.  `spatial` (BatchNorm(axis=(1, 2)) on an image tensor): one statistic per pixel
+// position p over the batch AND the C channels; otherwise (2-D input) one per internal column p * Cp + c over the batch.
+struct BnSite {
+    int layer;    // hidden layer whose post-ReLU activation it normalises (-1: the network input x / 255)
+    int spatial;
+    int P, C, Cp; // positions, channels, padded channels
+    int G, G_p;   // statistic groups (spatial: P; feature: P * Cp internal columns), padded to 8
+    int64_t scale_off, bias_off, mean_off, var_off;  // parameter buffer (floats): scale / bias are optimised, mean / var are the running averages
+    int64_t in_off, out_off, bmean_off, bvar_off, s1_off, s2_off;  // workspace (floats): S8 input / output rows, batch statistics, backward sums
+    char name[16];
+};
+
 struct Plan {
     ImpalaStack imp[IMP_STACKS];
     int n_layers;
     Layer L[MAX_LAYERS];
     int B, N2;
+    int bn;   // cfg->batch_norm
+    int Bb;   // rows the backward runs over: B (the next-state half has a zero cotangent, isdqn.py:99) -- N2 with BatchNorm, whose
+              // batch statistics carry the gradient into the next-state rows
+    int n_bn;
+    BnSite bns[MAX_LAYERS + 1];
+    int64_t x0_off;  // BatchNorm, cnn: the network input frames / 255 as S8 [N2][h * w][8]; fc: concat(state, next_state) fp32 [N2][obs]
     int n_heads, n_actions, nha, nha_p;
     // K regressed heads; head k + oh (online rows) is regressed on head k (next-state rows).  iS-DQN: n_heads = 1 + K,
     // oh = 1 (isdqn.py:96-98).  A single head (n_heads = 1) is TF-DQN: K = 1, oh = 0 -- the head is regressed on its own
@@ -98,9 +117,15 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
     ISDQN_REQUIRE(cfg->precision == ISDQN_PRECISION_BF16X3 || cfg->precision == ISDQN_PRECISION_BF16, ISDQN_ERR_ARG,
                   "bad precision");
     ISDQN_REQUIRE(cfg->huber_delta >= 0.f, ISDQN_ERR_ARG, "huber_delta must be >= 0 (0 = squared error)");
+    ISDQN_REQUIRE(cfg->batch_norm == 0 || cfg->batch_norm == 1, ISDQN_ERR_ARG, "batch_norm must be 0 or 1");
+    ISDQN_REQUIRE(!cfg->batch_norm || cfg->arch != ISDQN_ARCH_IMPALA, ISDQN_ERR_UNSUPPORTED, "BatchNorm inside the impala Stacks is not built (cnn and fc are)");
     P.regions.clear();
     P.B = cfg->batch_size;
     P.N2 = 2 * P.B;
+    P.bn = cfg->batch_norm;
+    P.Bb = P.bn ? P.N2 : P.B;
+    P.n_bn = 0;
+    P.x0_off = -1;
     P.n_heads = cfg->n_heads;
     P.K = cfg->n_heads >= 2 ? cfg->n_heads - 1 : 1;
     P.oh = cfg->n_heads >= 2 ? 1 : 0;
@@ -130,17 +155,36 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
         }
     };
 
+    // BatchNorm_i in call order (Flax auto-names per class): scale and bias join the optimised parameters here, the running
+    // averages are placed behind all of them (below)
+    auto add_bn = [&](int layer, int spatial, int Pn, int C, int Cp) {
+        BnSite& b = P.bns[P.n_bn];
+        memset(&b, 0, sizeof(b));
+        b.layer = layer; b.spatial = spatial; b.P = Pn; b.C = C; b.Cp = Cp;
+        b.G = spatial ? Pn : Pn * Cp;
+        b.G_p = round_up(b.G, 8);
+        b.scale_off = poff; poff += b.G_p;
+        b.bias_off = poff; poff += b.G_p;
+        snprintf(b.name, sizeof(b.name), "BatchNorm_%d", P.n_bn);
+        ++P.n_bn;
+    };
+
     if (cfg->arch == ISDQN_ARCH_CNN) {
         ISDQN_REQUIRE(cfg->obs_h >= 8 && cfg->obs_w >= 8 && cfg->obs_c >= 1 && cfg->obs_c <= 16, ISDQN_ERR_ARG,
                       "bad observation shape");
         int h = cfg->obs_h, w = cfg->obs_w, c = cfg->obs_c, c_p = cfg->obs_c;
+        if (P.bn) {  // dqn.py:52-53: the first convolution reads BatchNorm(x / 255): S8 rows of 8-padded channels, generic K order
+            ISDQN_REQUIRE(cfg->obs_c <= 8, ISDQN_ERR_UNSUPPORTED, "BatchNorm: at most 8 stacked frames");
+            c_p = 8;
+            add_bn(-1, 1, h * w, c, c_p);
+        }
         for (int i = 0; i < 3; ++i) {
             Layer& l = P.L[nl++];
             memset(&l, 0, sizeof(l));
             l.kind = 0;
             l.has_ln = cfg->layer_norm ? 1 : 0;
             l.has_relu = 1;
-            l.is_u8 = (i == 0);
+            l.is_u8 = (i == 0) && !P.bn;
             l.hin = h; l.win = w; l.cin = c; l.cin_p = c_p;
             l.ksz = KS[i]; l.stride = ST[i]; l.taps = KS[i] * KS[i];
             int pad_w;
@@ -159,6 +203,8 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
             l.w_size = (int64_t)l.cout_p * l.K;
             snprintf(l.name, sizeof(l.name), "Conv_%d", n_conv++);
             finish_params(l);
+            // dqn.py:59-60, 66-67: BatchNorm(axis=(1, 2)) behind the first two ReLUs; :72-74: behind the flatten (a 2-D tensor: per feature)
+            if (P.bn) add_bn(i, i < 2 ? 1 : 0, l.npix, l.cout, l.cout_p);
             h = l.hout; w = l.wout; c = l.cout; c_p = l.cout_p;
         }
         in_elems_p = h * w * c_p;
@@ -264,9 +310,14 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
         l.w_size = (int64_t)l.out_p * l.in_p;
         snprintf(l.name, sizeof(l.name), "Dense_%d", n_dense++);
         finish_params(l);
+        if (P.bn && !l.is_head) add_bn(nl - 1, 0, 1, l.out_f, l.out_p);  // dqn.py:100-101
         in_f = l.out_f; in_p = l.out_p; in_elems_p = l.out_p;
     }
     P.n_layers = nl;
+    for (int s = 0; s < P.n_bn; ++s) {  // batch_stats (running mean / var): behind every optimised tensor
+        P.bns[s].mean_off = poff; poff += P.bns[s].G_p;
+        P.bns[s].var_off = poff; poff += P.bns[s].G_p;
+    }
     P.n_params = poff;
 
     // ---- workspace ----
@@ -295,18 +346,19 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
         }
         if (!l.is_head) {
             l.act_off = region(std::string("act/") + l.name, (int64_t)P.N2 * l.out_elems_p);
-            l.z_off = region(std::string("z/") + l.name, (int64_t)P.B * l.out_elems_p);
-            l.dz_off = region(std::string("dz/") + l.name, (int64_t)P.B * l.out_elems_p);
+            l.z_off = region(std::string("z/") + l.name, (int64_t)P.Bb * l.out_elems_p);
+            l.dz_off = region(std::string("dz/") + l.name, (int64_t)P.Bb * l.out_elems_p);
             l.part_rows = LN_MAX_BLOCKS;
             if (l.kind == 1 && P.B > l.part_rows) l.part_rows = P.B;  // head chain: one row per workgroup, as few as one transition each
             l.part_off = -2;  // sized below, once the consumer layer's tiling is known
             l.red_off = region(std::string("red/") + l.name, 3 * (int64_t)l.out_p);
         }
-        if (i > 0 && (int64_t)P.B * l.in_elems_p > P.da_floats) P.da_floats = (int64_t)P.B * l.in_elems_p;
+        // (BatchNorm: the first convolution's data gradient is needed too -- the input BatchNorm's scale / bias gradient)
+        if ((i > 0 || (P.bn && l.kind == 0)) && (int64_t)P.Bb * l.in_elems_p > P.da_floats) P.da_floats = (int64_t)P.Bb * l.in_elems_p;
         // weight-gradient slabs: split the contraction (online pixels / batch rows) over workgroups
         if (l.kind == 0) {
             int tiles_n = ceil_div(l.K, 64);
-            int ksteps = ceil_div(P.B * l.npix, 32);
+            int ksteps = ceil_div(P.Bb * l.npix, 32);
             int s = 256 / tiles_n;
             if (s < 1) s = 1;
             if (s > ksteps) s = ksteps;
@@ -322,18 +374,18 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
                 if (wide) ntw = l.K / 64;
                 if (ntw) {
                     int ncg = l.K / (64 * ntw);
-                    int G = (P.B * ncg + 255) / 256;
-                    if (wide) G = (P.B + 127) / 128;  // ~128 workgroups of two images: measured best (1: 2681, 2: 2806 steps/s)
+                    int G = (P.Bb * ncg + 255) / 256;
+                    if (wide) G = (P.Bb + 127) / 128;  // ~128 workgroups of two images: measured best (1: 2681, 2: 2806 steps/s)
                     if (G < 1) G = 1;
                     l.wgi_ntw = ntw;
                     l.wgi_G = G;
-                    l.wgi_groups = ceil_div(P.B, G);
+                    l.wgi_groups = ceil_div(P.Bb, G);
                     if (l.wgi_groups > l.gw_slabs) l.gw_slabs = l.wgi_groups;
                 }
             }
         } else if (l.kind == 1) {
             int tiles = ceil_div(l.out_p, 128) * ceil_div(l.in_p, 128);
-            int ksteps = ceil_div(P.B, 32);
+            int ksteps = ceil_div(P.Bb, 32);
             int s = tiles >= 128 ? 1 : 256 / tiles;
             if (s > ksteps) s = ksteps;
             if (s < 1) s = 1;
@@ -400,8 +452,26 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
             }
         }
     }
+    for (int s = 0; s < P.n_bn; ++s) {
+        BnSite& b = P.bns[s];
+        const std::string pre = std::string("bn/") + b.name + "/";
+        const int64_t width = (int64_t)b.P * b.Cp;
+        if (b.layer < 0) {
+            P.x0_off = region("bn/x0", (int64_t)P.N2 * width);
+            b.in_off = P.x0_off;
+        } else {
+            b.in_off = P.L[b.layer].act_off;
+        }
+        b.out_off = region(pre + "out", (int64_t)P.N2 * width);
+        b.bmean_off = region(pre + "mean", b.G_p);
+        b.bvar_off = region(pre + "var", b.G_p);
+        b.s1_off = region(pre + "dbias", b.G_p);
+        b.s2_off = region(pre + "dscale", b.G_p);
+    }
+    if (P.bn && cfg->arch == ISDQN_ARCH_FC)  // concat(state, next_state) as one matrix (the first layer's weight gradient contracts over all 2B rows)
+        P.x0_off = region("bn/x0", (int64_t)P.N2 * P.L[0].in_f);
     P.q_off = region("q", (int64_t)P.N2 * P.nha_p);
-    P.dout_off = region("dout", (int64_t)P.B * P.nha_p);
+    P.dout_off = region("dout", (int64_t)P.Bb * P.nha_p);
     P.da_off = region("da", P.da_floats);
     P.slab_off = region("slab", P.slab_floats);
     P.qv_off = region("q_values", (int64_t)P.B * P.K);

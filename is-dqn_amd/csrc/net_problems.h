@@ -542,9 +542,10 @@ struct ConvDgrad {
     const float* dz;  // [n_img][hout][wout][cout_p]
     float* da;        // [n_img][hin][win][cin_p]
     int n_img, T, Kc; // T = ksz/stride taps per dim per class, Kc = T*T*cout_p
-    int tile_start[5];   // prefix of tiles per class (stride^2 <= 4 classes)
+    int tile_start[17];  // prefix of tiles per class (stride^2 <= 16 classes: the 8x8 / 4 first convolution's data gradient exists
+                         // only under BatchNorm, whose input site has parameters of its own)
     int n_classes;
-    FastDiv cls_d_hw[4], cls_d_w[4];  // per class: divide by Ha*Wb and by Wb
+    FastDiv cls_d_hw[16], cls_d_w[16];  // per class: divide by Ha*Wb and by Wb
     struct Tile { int m0, n0, k0, k1, cy, cx, py, px, Ha, Wb, Nc; FastDiv d_hw, d_w; };
     struct ACtx { int ci0; };
     struct BCtx { int j, oyb, oxb, valid; };

@@ -36,6 +36,7 @@ class QNetEngine:
         precision: str = "bf16x3",
         device: str | None = None,
         huber_delta: float = 0.0,
+        batch_norm: bool = False,
     ):
         _hip.require_gpu()
         self.lib = _hip.lib()
@@ -70,6 +71,8 @@ class QNetEngine:
         cfg.adam_b1, cfg.adam_b2 = 0.9, 0.999
         cfg.adam_eps = float(adam_eps)
         cfg.huber_delta = float(huber_delta)  # 0: the reference's squared TD error
+        cfg.batch_norm = 1 if batch_norm else 0  # architectures/dqn.py:52-53, 59-60, 66-67, 73-74, 100-101 (csrc/batchnorm.h)
+        self.batch_norm = bool(batch_norm)
         self.cfg = cfg
         self.features = feats
         self.architecture_type = architecture_type
@@ -113,7 +116,7 @@ class QNetEngine:
         d = list(info.dims)
         if info.kind == 0:
             k1, k2, cin, cout = arr.shape
-            if self.architecture_type == "cnn" and info.layer == 0:
+            if self.architecture_type == "cnn" and info.layer == 0 and not self.batch_norm:
                 out = np.zeros((d[0], cin, k1 * k2), np.float32)  # [out][plane][ky*8+kx]
                 out[:cout] = arr.transpose(3, 2, 0, 1).reshape(cout, cin, k1 * k2)
             else:
@@ -133,6 +136,13 @@ class QNetEngine:
             else:
                 out[:out_f, :in_f] = arr.T
             return out.reshape(-1)
+        if info.kind >= 5:  # BatchNorm_i scale / bias / mean / var: dims = [groups, P, C, C padded]
+            out = np.zeros(info.size, np.float32)
+            if info.ndim == 2:  # spatial site: one value per pixel position, flax shape (H, W)
+                out[: d[0]] = arr.reshape(-1)
+            else:  # feature site: flax column p * C + c -> internal column p * Cp + c
+                out[: d[0]].reshape(d[1], d[3])[:, : d[2]] = arr.reshape(d[1], d[2])
+            return out
         out = np.zeros(d[0], np.float32)
         out[: arr.shape[0]] = arr
         return out
@@ -142,7 +152,7 @@ class QNetEngine:
         shape = tuple(info.flax_shape[: info.ndim])
         if info.kind == 0:
             k1, k2, cin, cout = shape
-            if self.architecture_type == "cnn" and info.layer == 0:
+            if self.architecture_type == "cnn" and info.layer == 0 and not self.batch_norm:
                 w = flat.reshape(d[0], cin, k1, k2)[:cout]
                 return np.ascontiguousarray(w.transpose(2, 3, 1, 0))
             w = flat.reshape(d[0], k1, k2, d[2])[:cout, :, :, :cin]
@@ -158,14 +168,25 @@ class QNetEngine:
             else:
                 w = w[:, :in_f]
             return np.ascontiguousarray(w.T)
+        if info.kind >= 5:
+            if info.ndim == 2:
+                return flat[: d[0]].reshape(shape).copy()
+            return np.ascontiguousarray(flat[: d[0]].reshape(d[1], d[3])[:, : d[2]]).reshape(shape)
         return flat[: shape[0]].copy()
 
-    def import_flax(self, params: Dict[str, Dict[str, np.ndarray]], target: torch.Tensor | None = None) -> None:
-        """Load a reference-layout pytree ({"Conv_0": {"kernel": HWIO, "bias"}, "LayerNorm_0": ...})."""
+    def import_flax(self, params: Dict[str, Dict[str, np.ndarray]], target: torch.Tensor | None = None, batch_stats=None) -> None:
+        """Load a reference-layout pytree ({"Conv_0": {"kernel": HWIO, "bias"}, "LayerNorm_0": ...}).  BatchNorm networks: the
+        running averages come from ``batch_stats`` ({"BatchNorm_0": {"mean", "var"}}, Flax's second collection); without it
+        they keep Flax's initial values (mean 0, var 1)."""
         flat = np.zeros(self.n_param_floats, np.float32)
         for info in self.infos:
             mod, leaf = info.name.decode().rsplit("/", 1)  # (impala: "Stack_0/Conv_1" / "kernel")
-            v = self._to_internal(info, params[mod][leaf])
+            if info.kind >= 7:
+                shape = tuple(info.flax_shape[: info.ndim])
+                src = batch_stats[mod][leaf] if batch_stats is not None else (np.zeros(shape, np.float32) if info.kind == 7 else np.ones(shape, np.float32))
+                v = self._to_internal(info, src)
+            else:
+                v = self._to_internal(info, params[mod][leaf])
             assert v.size == info.size, (info.name, v.size, info.size)
             flat[info.offset : info.offset + info.size] = v
         (self.params if target is None else target).copy_(torch.from_numpy(flat))
@@ -174,8 +195,20 @@ class QNetEngine:
         flat = (self.params if source is None else source).detach().cpu().numpy()
         out: Dict[str, Dict[str, np.ndarray]] = {}
         for info in self.infos:
+            if info.kind >= 7:  # (running averages: export_batch_stats)
+                continue
             mod, leaf = info.name.decode().rsplit("/", 1)  # (impala: "Stack_0/Conv_1" / "kernel")
             out.setdefault(mod, {})[leaf] = self._from_internal(info, flat[info.offset : info.offset + info.size])
+        return out
+
+    def export_batch_stats(self, source: torch.Tensor | None = None) -> Dict[str, Dict[str, np.ndarray]]:
+        """Flax's ``batch_stats`` collection of a BatchNorm network: {"BatchNorm_i": {"mean", "var"}} (empty without BatchNorm)."""
+        flat = (self.params if source is None else source).detach().cpu().numpy()
+        out: Dict[str, Dict[str, np.ndarray]] = {}
+        for info in self.infos:
+            if info.kind >= 7:
+                mod, leaf = info.name.decode().rsplit("/", 1)
+                out.setdefault(mod, {})[leaf] = self._from_internal(info, flat[info.offset : info.offset + info.size])
         return out
 
     def init_params(self, seed: int) -> None:
@@ -207,8 +240,10 @@ class QNetEngine:
                         filled += draw.size
                     w = w.reshape(shape) * std
                 params.setdefault(mod, {})[leaf] = w.astype(np.float32)
-            elif info.kind == 3:
+            elif info.kind in (3, 5):  # LayerNorm / BatchNorm scale
                 params.setdefault(mod, {})[leaf] = np.ones(shape, np.float32)
+            elif info.kind >= 7:  # running averages: import_flax's defaults (mean 0, var 1)
+                continue
             else:
                 params.setdefault(mod, {})[leaf] = np.zeros(shape, np.float32)
         self.import_flax(params)

@@ -43,6 +43,7 @@ class NetConfig(ctypes.Structure):
         ("adam_b2", c_float),
         ("adam_eps", c_float),
         ("huber_delta", c_float),
+        ("batch_norm", c_int32),
     ]
 
 

@@ -27,7 +27,13 @@ class DeviceParams:
             node.update(leaves)
         return out
 
+    def batch_stats(self):
+        """Flax's second collection of a BatchNorm network (isdqn.py:87-88): {"BatchNorm_i": {"mean", "var"}}."""
+        return self._engine.export_batch_stats(self.tensor)
+
     def __getitem__(self, key):
+        if key == "batch_stats" and self._engine.batch_norm:
+            return self.batch_stats()
         if key != "params":
             raise KeyError(key)
         return self.to_flax()
@@ -51,8 +57,9 @@ class EngineAgent:
     """Common state: ``n_heads`` network heads of ``n_actions`` outputs each on the HIP engine."""
 
     def _init_engine_agent(self, key, observation_dim, n_actions, n_heads, features, layer_norm, architecture_type,
-                           learning_rate, gamma, update_horizon, adam_eps, batch_size, precision, device, huber_delta=0.0):
+                           learning_rate, gamma, update_horizon, adam_eps, batch_size, precision, device, huber_delta=0.0, batch_norm=False):
         self.n_actions = n_actions
+        self.batch_norm = bool(batch_norm)
         self._n_heads = int(n_heads)
         self.features = [int(f) for f in features]
         self.architecture_type = architecture_type
@@ -77,7 +84,7 @@ class EngineAgent:
         eng = QNetEngine(
             self.observation_dim, self.n_actions, self._n_heads, self.features, self.architecture_type,
             self.layer_norm, batch_size, gamma_n=self.gamma**self.update_horizon, learning_rate=self.learning_rate,
-            adam_eps=self.adam_eps, precision=self.precision, device=self.device, huber_delta=self.huber_delta,
+            adam_eps=self.adam_eps, precision=self.precision, device=self.device, huber_delta=self.huber_delta, batch_norm=self.batch_norm,
         )
         if init:
             eng.init_params(self._seed)
@@ -113,7 +120,7 @@ class EngineAgent:
             tree = {**{f"{k}/{m}": v for k, sub in tree.items() if k.startswith("Stack_") for m, v in sub.items()},
                     **{k: v for k, v in tree.items() if not k.startswith("Stack_")}}
         t = torch.empty_like(self._engine.params)
-        self._engine.import_flax(tree, target=t)
+        self._engine.import_flax(tree, target=t, batch_stats=params.get("batch_stats") if "params" in params else None)
         return t
 
     # ------------------------------------------------------------------ batches
@@ -311,4 +318,6 @@ class EngineAgent:
         return self._engine.forward(n_rows=1, params=self._bind(params), **self._obs_to_device(state))
 
     def get_model(self):
+        if self.batch_norm:  # Flax keeps the running averages in a second collection beside "params" (isdqn.py:87-88)
+            return {"params": self.params.to_flax(), "batch_stats": self.params.batch_stats()}
         return {"params": self.params.to_flax()}

@@ -49,8 +49,6 @@ class iSDQN(EngineAgent):
         huber_delta: float = 0.0,
     ):
         """``huber_delta``: 0 keeps the reference's squared TD error (isdqn.py:102); > 0 trains on the Huber loss."""
-        if batch_norm:
-            raise NotImplementedError("BatchNorm variants are outside the hot-path scope (SURVEY.md section 8)")
         self.n_bellman_iterations = n_bellman_iterations
         self.last_idx_mlp = len(features) if architecture_type == "fc" else len(features) - 3
         self.network = DQNNet([int(f) for f in features], architecture_type, (1 + n_bellman_iterations) * n_actions, layer_norm, batch_norm)
@@ -61,7 +59,7 @@ class iSDQN(EngineAgent):
         self.use_graph = bool(use_graph)
         self.priority_writeback = False
         self._init_engine_agent(key, observation_dim, n_actions, 1 + n_bellman_iterations, features, layer_norm, architecture_type,
-                                learning_rate, gamma, update_horizon, adam_eps, batch_size, precision, device, huber_delta)
+                                learning_rate, gamma, update_horizon, adam_eps, batch_size, precision, device, huber_delta, batch_norm)
         self._action_rng = np.random.default_rng(self._seed + 1)
         self.cumulated_losses = np.zeros(self.n_bellman_iterations)
 

@@ -32,13 +32,11 @@ class TFDQN(EngineAgent):
         precision: str = "bf16x3",
         device: str | None = None,
     ):
-        if batch_norm:
-            raise NotImplementedError("BatchNorm variants are outside the hot-path scope (SURVEY.md section 8)")
         self.network = DQNNet([int(f) for f in features], architecture_type, n_actions, layer_norm, batch_norm)
         self.data_to_update = data_to_update
         self.target_update_frequency = target_update_frequency
         self._init_engine_agent(key, observation_dim, n_actions, 1, features, layer_norm, architecture_type, learning_rate,
-                                gamma, update_horizon, adam_eps, batch_size, precision, device)
+                                gamma, update_horizon, adam_eps, batch_size, precision, device, batch_norm=batch_norm)
         self.cumulated_loss = 0
 
     # ------------------------------------------------------------------ tfdqn.py:38-54

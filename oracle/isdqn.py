@@ -15,6 +15,10 @@ reference ``slimdqn/networks/isdqn.py``:
   * compute_target ............. :105-109 (r + (1-terminal) * gamma**n * max_a)
   * shift_params ............... :111-125 (head k <- head k+1, moments untouched)
   * best_action ................ :127-135 (head 1+idx)
+  * batch_norm=True (cnn / fc) . :40, 87-88, 95, 130: loss / learn run the network in training mode on concat(state, next_state)
+                                  (batch statistics; the gradient flows through them into BOTH halves), learn_on_batch keeps the
+                                  moved running averages (``self.batch_stats``: Flax's second collection, kept beside the
+                                  parameter dict here), best_action uses them (use_running_average=True)
 """
 from __future__ import annotations
 
@@ -48,7 +52,7 @@ class iSDQN:
         """``huber_delta``: 0 = the reference's squared TD error (isdqn.py:102); > 0 = Huber loss (optax.huber_loss: 0.5 d^2 for
         |d| <= delta, delta (|d| - delta / 2) beyond) -- the north star's wording, not in the reference."""
         self.huber_delta = float(huber_delta)
-        assert not batch_norm, "BatchNorm variants are out of the hot-path scope (SURVEY.md section 8)"
+        self.batch_norm = bool(batch_norm)
         self.n_bellman_iterations = n_bellman_iterations
         self.n_actions = n_actions
         self.features = [int(f) for f in features]
@@ -59,9 +63,11 @@ class iSDQN:
         self.dtype = dtype
         if params is None:
             params = net.init_params(
-                int(key), observation_dim, self.features, architecture_type, self.final_feature, layer_norm
+                int(key), observation_dim, self.features, architecture_type, self.final_feature, layer_norm, batch_norm=self.batch_norm
             )
         self.params = net.to_torch(params, dtype)
+        self.batch_stats = net.to_torch(net.init_batch_stats(params), dtype) if self.batch_norm else None
+        self._new_stats = None
         self.optimizer_state = {
             "count": 0,
             "mu": {m: {n: torch.zeros_like(t) for n, t in l.items()} for m, l in self.params.items()},
@@ -76,10 +82,13 @@ class iSDQN:
         self.cumulated_losses = np.zeros(self.n_bellman_iterations)
 
     # -- network ---------------------------------------------------------------
-    def apply(self, params, state):
-        """(N, 1+K, A) head view of the network output."""
+    def apply(self, params, state, use_running_average: bool = False):
+        """(N, 1+K, A) head view of the network output.  BatchNorm: training mode unless ``use_running_average`` (the moved
+        running averages of a training-mode call are left in ``self._new_stats``: isdqn.py:40 returns them as batch_stats)."""
         state = torch.as_tensor(np.asarray(state)) if not torch.is_tensor(state) else state
-        q = net.forward(params, state, self.features, self.architecture_type, self.layer_norm)
+        self._new_stats = {} if (self.batch_norm and not use_running_average) else None
+        q = net.forward(params, state, self.features, self.architecture_type, self.layer_norm, batch_norm=self.batch_norm,
+                        batch_stats=self.batch_stats, use_running_average=use_running_average, new_stats=self._new_stats)
         return q.reshape(-1, 1 + self.n_bellman_iterations, self.n_actions)
 
     # -- trainer-facing cadence -------------------------------------------------
@@ -147,6 +156,8 @@ class iSDQN:
 
     def learn_on_batch(self, params, optimizer_state, samples):
         grads, per_head = self.grads(params, samples)
+        if self.batch_norm:  # params["batch_stats"] = batch_stats["batch_stats"] (isdqn.py:87-88)
+            self.batch_stats = {m: {n: t.detach().to(self.dtype) for n, t in l.items()} for m, l in self._new_stats.items()}
         count = optimizer_state["count"] + 1
         b1, b2 = net.ADAM_B1, net.ADAM_B2
         c1 = 1.0 - b1**count
@@ -182,8 +193,10 @@ class iSDQN:
         draw is an input here because threefry is not reproducible offline.
         """
         state = torch.as_tensor(np.asarray(state))
-        q = self.apply(params, state[None])[0]
+        q = self.apply(params, state[None], use_running_average=True)[0]
         return int(torch.argmax(q[1 + idx_network]))
 
     def get_model(self):
+        if self.batch_norm:
+            return {"params": net.to_numpy(self.params), "batch_stats": net.to_numpy(self.batch_stats)}
         return {"params": net.to_numpy(self.params)}

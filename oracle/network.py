@@ -20,6 +20,13 @@ documented behaviour of those versions at the reference's own call sites:
         lecun_normal (truncated normal, std sqrt(1/fan_in)/0.87962566103423978) for fc;
         biases 0, LayerNorm scale 1 / bias 0.  (JAX threefry streams are not
         reproducible offline: draws come from numpy PCG64 instead.)
+  * ``nn.BatchNorm`` (batch_norm=True) ......... dqn.py:52-53, 59-60, 66-67, 73-74, 100-101 -- flax 0.10.2 defaults: momentum 0.99,
+        epsilon 1e-5, use_fast_variance (var = max(0, E[x^2] - E[x]^2)), scale 1 / bias 0, batch_stats mean 0 / var 1;
+        ``axis`` names the FEATURE axes: ``BatchNorm(use_running_average, axis=(1, 2))`` on (N, H, W, C) keeps one statistic and
+        one (scale, bias) per pixel position (h, w) and reduces over the batch AND the channels; the default axis=-1 on the
+        flattened / dense (N, F) tensors is per feature.  y = (x - mean) * (rsqrt(var + eps) * scale) + bias.  Training-mode
+        calls (apply_fn with mutable batch_stats, isdqn.py:40, 95) use the batch statistics and move the running averages
+        ra = 0.99 ra + 0.01 batch; best_action (isdqn.py:130) passes use_running_average=True.  cnn and fc only here.
   * iSDQN.loss_on_batch / compute_target ....... slimdqn/networks/isdqn.py:92-109
   * iSDQN.learn_on_batch (grad + optax.adam) ... isdqn.py:82-90, 46
         adam: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; t += 1 ;
@@ -41,6 +48,7 @@ import torch
 import torch.nn.functional as F
 
 LN_EPS = 1e-6
+BN_EPS, BN_MOMENTUM = 1e-5, 0.99
 ADAM_B1, ADAM_B2 = 0.9, 0.999
 
 # (kernel, stride) of the three cnn torso convolutions (dqn.py:55, 62, 69)
@@ -88,10 +96,20 @@ def init_params(
     architecture_type: str,
     final_feature: int,
     layer_norm: bool,
+    batch_norm: bool = False,
 ) -> Dict[str, Dict[str, np.ndarray]]:
-    """Flax-layout parameter pytree (the inner ``params["params"]`` dict), float32."""
+    """Flax-layout parameter pytree (the inner ``params["params"]`` dict), float32.  ``batch_norm``: BatchNorm_i scale / bias
+    join it in call order (the running averages are a second collection: ``init_batch_stats``)."""
     rng = np.random.default_rng(seed)
     params: Dict[str, Dict[str, np.ndarray]] = {}
+    n_bn = 0
+
+    def add_bn(shape):
+        nonlocal n_bn
+        if batch_norm:
+            params[f"BatchNorm_{n_bn}"] = {"scale": np.ones(shape, np.float32), "bias": np.zeros(shape, np.float32)}
+            n_bn += 1
+
 
     def xavier(shape, fan_in, fan_out):
         lim = math.sqrt(6.0 / (fan_in + fan_out))
@@ -121,6 +139,7 @@ def init_params(
 
     if architecture_type == "cnn":
         h, w, c = observation_dim
+        add_bn((h, w))  # dqn.py:52-53: BatchNorm(axis=(1, 2)) on x / 255
         for i, (k, s) in enumerate(CNN_GEOMETRY):
             cout = int(features[i])
             params[f"Conv_{n_conv}"] = {
@@ -132,10 +151,12 @@ def init_params(
             h = same_padding(h, k, s)[0]
             w = same_padding(w, k, s)[0]
             c = cout
+            add_bn((h, w) if i < 2 else (h * w * c,))  # :59-60, 66-67 on the image tensor; :72-74 behind the flatten
         width = h * w * c
         dense_feats = [int(f) for f in features[3:]]
         init = lambda shape: xavier(shape, shape[0], shape[1])
     elif architecture_type == "impala":
+        assert not batch_norm, "BatchNorm inside the impala Stacks is not restated"
         # dqn.py:75-88 + Stack (dqn.py:7-36): three stacks of conv3x3 -> max_pool 3x3 / 2 SAME -> two residual blocks
         # ([LayerNorm] -> relu -> conv3x3 -> relu -> conv3x3 -> + input); modules are auto-named per class INSIDE each Stack
         # (Conv_0 .. Conv_4, LayerNorm_0 .. LayerNorm_1), the Stacks Stack_0 .. Stack_2, and the LayerNorm behind the last stack
@@ -166,6 +187,7 @@ def init_params(
         params[f"Dense_{n_dense}"] = {"kernel": init((width, f)), "bias": np.zeros(f, np.float32)}
         n_dense += 1
         add_ln(f)
+        add_bn((f,))  # dqn.py:100-101
         width = f
     params[f"Dense_{n_dense}"] = {
         "kernel": init((width, final_feature)),
@@ -174,7 +196,32 @@ def init_params(
     return params
 
 
+def init_batch_stats(params) -> Dict[str, Dict[str, np.ndarray]]:
+    """Flax's ``batch_stats`` collection at initialisation: mean 0, var 1 with the shape of each BatchNorm_i's scale."""
+    return {m: {"mean": np.zeros_like(np.asarray(l["scale"]), dtype=np.float32), "var": np.ones_like(np.asarray(l["scale"]), dtype=np.float32)}
+            for m, l in params.items() if m.startswith("BatchNorm_")}
+
+
 # ----------------------------------------------------------------------------- torch forward
+def _batch_norm(x: torch.Tensor, p, stats, use_running_average: bool, spatial: bool, new_stats, name: str) -> torch.Tensor:
+    """flax.linen.BatchNorm: ``spatial`` = axis=(1, 2) on (N, H, W, C) -- features (H, W), reduction over (N, C); else axis=-1 on
+    (N, F).  ``new_stats[name]`` receives the moved running averages of a training-mode call."""
+    red = (0, 3) if spatial else (0,)
+    if use_running_average:
+        mean, var = stats[name]["mean"], stats[name]["var"]
+    else:
+        mean = x.mean(dim=red)
+        var = torch.clamp((x * x).mean(dim=red) - mean * mean, min=0.0)
+        if new_stats is not None:
+            new_stats[name] = {"mean": (BN_MOMENTUM * stats[name]["mean"] + (1 - BN_MOMENTUM) * mean).detach(),
+                               "var": (BN_MOMENTUM * stats[name]["var"] + (1 - BN_MOMENTUM) * var).detach()}
+    if spatial:
+        mean, var, scale, bias = (t[None, :, :, None] for t in (mean, var, p["scale"], p["bias"]))
+    else:
+        scale, bias = p["scale"], p["bias"]
+    return (x - mean) * (torch.rsqrt(var + BN_EPS) * scale) + bias
+
+
 def _layer_norm(x: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     mean = x.mean(dim=-1, keepdim=True)
     mean2 = (x * x).mean(dim=-1, keepdim=True)
@@ -223,18 +270,33 @@ def _impala_stack(params, prefix: str, x: torch.Tensor, layer_norm: bool, captur
     return x
 
 
-def forward(params, x, features, architecture_type: str, layer_norm: bool, capture: dict | None = None):
+def forward(params, x, features, architecture_type: str, layer_norm: bool, capture: dict | None = None, batch_norm: bool = False,
+            batch_stats=None, use_running_average: bool = False, new_stats: dict | None = None):
     """DQNNet.__call__ (dqn.py:47-103) for a batch.  ``params``: dict of dicts of torch tensors.
+    ``batch_norm``: ``batch_stats`` holds the running averages ({"BatchNorm_i": {"mean", "var"}} of torch tensors);
+    training-mode calls (use_running_average=False) normalise with the batch statistics and write the moved averages to ``new_stats``.
 
     x: (N,84,84,4) raw pixel values (any dtype; converted, then /255) for cnn, (N,obs) for fc.
     Returns (N, final_feature).  ``capture`` (optional dict) receives the post-activation of
     every hidden layer under the module name that produced it.
     """
     dtype = next(iter(next(iter(params.values())).values())).dtype
-    n_ln = n_dense = 0
+    n_ln = n_dense = n_bn = 0
     x = x.to(dtype)
+
+    def bn(x, spatial):
+        nonlocal n_bn
+        if not batch_norm:
+            return x
+        name = f"BatchNorm_{n_bn}"
+        n_bn += 1
+        y = _batch_norm(x, params[name], batch_stats, use_running_average, spatial, new_stats, name)
+        if capture is not None:
+            capture[name] = y
+        return y
+
     if architecture_type == "cnn":
-        x = x / 255.0
+        x = bn(x / 255.0, True)
         for i, (_k, s) in enumerate(CNN_GEOMETRY):
             p = params[f"Conv_{i}"]
             x = _conv_same(x, p["kernel"], p["bias"], s)
@@ -245,9 +307,12 @@ def forward(params, x, features, architecture_type: str, layer_norm: bool, captu
             x = torch.relu(x)
             if capture is not None:
                 capture[f"Conv_{i}"] = x
-        x = x.reshape(x.shape[0], -1)
+            if i < 2:
+                x = bn(x, True)
+        x = bn(x.reshape(x.shape[0], -1), False)
         start = 3
     elif architecture_type == "impala":  # dqn.py:75-88
+        assert not batch_norm
         x = x / 255.0
         for s_idx in range(3):
             x = _impala_stack(params, f"Stack_{s_idx}", x, layer_norm, capture)
@@ -272,6 +337,7 @@ def forward(params, x, features, architecture_type: str, layer_norm: bool, captu
         x = torch.relu(x)
         if capture is not None:
             capture[f"Dense_{n_dense}"] = x
+        x = bn(x, False)
         n_dense += 1
     p = params[f"Dense_{n_dense}"]
     return x @ p["kernel"] + p["bias"]

@@ -34,8 +34,8 @@ def make_frame_batch(B, n_actions, seed=0, h=84, w=84, stack=4, n_frames=None, z
     return frames, ids, action, reward, terminal, ref
 
 
-def perturbed_params(seed, obs, feats, arch, final_feature, layer_norm, scale=0.1):
-    p = onet.init_params(seed, obs, feats, arch, final_feature, layer_norm)
+def perturbed_params(seed, obs, feats, arch, final_feature, layer_norm, scale=0.1, batch_norm=False):
+    p = onet.init_params(seed, obs, feats, arch, final_feature, layer_norm, batch_norm=batch_norm)
     rng = np.random.default_rng(seed + 1)
     for m in p:
         for n in p[m]:
@@ -45,15 +45,22 @@ def perturbed_params(seed, obs, feats, arch, final_feature, layer_norm, scale=0.
 
 
 def make_pair(feats, K, A, B, arch="cnn", obs=(84, 84, 4), layer_norm=True, precision="bf16x3", seed=0,
-              lr=1e-3, gamma=0.99, n=1, adam_eps=1.5e-4, dtype=torch.float32):
+              lr=1e-3, gamma=0.99, n=1, adam_eps=1.5e-4, dtype=torch.float32, batch_norm=False):
+    """``batch_norm``: both sides also start from the same (non-trivial) running averages."""
     from slimdqn._engine import QNetEngine
 
-    params = perturbed_params(seed, obs, feats, arch, (1 + K) * A, layer_norm)
-    oracle = OracleAgent(seed, obs, A, K, list(feats), layer_norm, False, arch, lr, gamma, n, 1, 1,
+    params = perturbed_params(seed, obs, feats, arch, (1 + K) * A, layer_norm, batch_norm=batch_norm)
+    oracle = OracleAgent(seed, obs, A, K, list(feats), layer_norm, batch_norm, arch, lr, gamma, n, 1, 1,
                          adam_eps=adam_eps, dtype=dtype, params=params)
     eng = QNetEngine(obs, A, 1 + K, feats, arch, layer_norm, B, gamma_n=gamma**n, learning_rate=lr,
-                     adam_eps=adam_eps, precision=precision)
-    eng.import_flax(params)
+                     adam_eps=adam_eps, precision=precision, batch_norm=batch_norm)
+    stats = None
+    if batch_norm:
+        rng = np.random.default_rng(seed + 2)
+        stats = {m: {"mean": rng.normal(0, 0.3, l["mean"].shape).astype(np.float32), "var": rng.uniform(0.5, 2.0, l["var"].shape).astype(np.float32)}
+                 for m, l in onet.init_batch_stats(params).items()}
+        oracle.batch_stats = onet.to_torch(stats, dtype)
+    eng.import_flax(params, batch_stats=stats)
     return oracle, eng, params
 
 
