@@ -23,6 +23,9 @@ class AnalysisDQN(iSDQN):
     def __init__(self, *args, **kwargs):
         kwargs["use_graph"] = False  # every update reads diagnostics back: nothing to capture
         super().__init__(*args, **kwargs)
+        if self.batch_norm:
+            raise NotImplementedError("the analysis agents are not built for BatchNorm networks (gradient-only and loss passes with "
+                                      "separate target parameters: include/isdqn_hip.h, batch_norm)")
         self.target_params = self.params.clone()  # analysisdqn.py:49
         K = self.n_bellman_iterations
         self.cumulated_target_churns_train = np.zeros(K)

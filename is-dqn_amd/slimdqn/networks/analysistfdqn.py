@@ -9,6 +9,9 @@ from slimdqn.networks.tfdqn import TFDQN
 class AnalysisTFDQN(TFDQN):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        if self.batch_norm:
+            raise NotImplementedError("the analysis agents are not built for BatchNorm networks (gradient-only and loss passes with "
+                                      "separate target parameters: include/isdqn_hip.h, batch_norm)")
         self.cumulated_target_churn_train = 0.0
         self.cumulated_target_churn_eval = 0.0
 

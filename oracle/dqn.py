@@ -8,7 +8,10 @@ tests/test_tfdqn.py hold formulas (target, loss, best action), restated as prope
           learn_on_batch :59-72, loss_on_batch :74-76 (mean over the batch of the per-sample loss :78-82),
           compute_target :84-88 (next state through the TARGET parameters), best_action :90-93
   * TFDQN follows slimdqn/networks/tfdqn.py: update_* :38-54 (no target copy), learn_on_batch :56-64,
-          loss_on_batch :66-80 (one forward on concat(state, next_state), stop-gradient target), compute_target :82-86
+          loss_on_batch :66-80 (one forward on concat(state, next_state), stop-gradient target), compute_target :82-86;
+          batch_norm=True (:62-63, 69-71, 91): training-mode forward with mutable batch_stats, learn_on_batch keeps the moved running
+          averages, best_action uses them.  (DQN has no batch_norm argument: dqn.py:14-27, and dqn.py:86 applies the network
+          without a mutable collection.)
 """
 from __future__ import annotations
 
@@ -23,15 +26,18 @@ class _OneHead:
     """Pieces both baselines share: parameters, Adam state, forward, acting."""
 
     def _init_common(self, key, observation_dim, n_actions, features, layer_norm, architecture_type, learning_rate, gamma,
-                     update_horizon, data_to_update, target_update_frequency, adam_eps, dtype, params):
+                     update_horizon, data_to_update, target_update_frequency, adam_eps, dtype, params, batch_norm=False):
+        self.batch_norm = bool(batch_norm)
         self.n_actions = n_actions
         self.features = [int(f) for f in features]
         self.architecture_type = architecture_type
         self.layer_norm = layer_norm
         self.dtype = dtype
         if params is None:
-            params = net.init_params(int(key), observation_dim, self.features, architecture_type, n_actions, layer_norm)
+            params = net.init_params(int(key), observation_dim, self.features, architecture_type, n_actions, layer_norm, batch_norm=self.batch_norm)
         self.params = net.to_torch(params, dtype)
+        self.batch_stats = net.to_torch(net.init_batch_stats(params), dtype) if self.batch_norm else None
+        self._new_stats = None
         self.optimizer_state = {
             "count": 0,
             "mu": {m: {n: torch.zeros_like(t) for n, t in l.items()} for m, l in self.params.items()},
@@ -42,9 +48,11 @@ class _OneHead:
         self.data_to_update, self.target_update_frequency = data_to_update, target_update_frequency
         self.cumulated_loss = 0.0
 
-    def apply(self, params, state):
+    def apply(self, params, state, use_running_average: bool = False):
         state = torch.as_tensor(np.asarray(state)) if not torch.is_tensor(state) else state
-        return net.forward(params, state, self.features, self.architecture_type, self.layer_norm)  # (N, A)
+        self._new_stats = {} if (self.batch_norm and not use_running_average) else None
+        return net.forward(params, state, self.features, self.architecture_type, self.layer_norm, batch_norm=self.batch_norm,
+                           batch_stats=self.batch_stats, use_running_average=use_running_average, new_stats=self._new_stats)  # (N, A)
 
     _batch_tensors = _Shared._batch_tensors
 
@@ -74,9 +82,11 @@ class _OneHead:
         return {m: {n: next(it) for n in l} for m, l in params.items()}, float(loss.detach())
 
     def best_action(self, params, state, **kwargs):
-        return int(torch.argmax(self.apply(params, torch.as_tensor(np.asarray(state))[None])[0]))
+        return int(torch.argmax(self.apply(params, torch.as_tensor(np.asarray(state))[None], use_running_average=self.batch_norm)[0]))
 
     def get_model(self):
+        if self.batch_norm:
+            return {"params": net.to_numpy(self.params), "batch_stats": net.to_numpy(self.batch_stats)}
         return {"params": net.to_numpy(self.params)}
 
 
@@ -124,9 +134,8 @@ class DQN(_OneHead):
 class TFDQN(_OneHead):
     def __init__(self, key, observation_dim, n_actions, features, layer_norm, batch_norm, architecture_type, learning_rate,
                  gamma, update_horizon, data_to_update, target_update_frequency, adam_eps=1e-8, dtype=torch.float32, params=None):
-        assert not batch_norm, "BatchNorm variants are out of the hot-path scope (SURVEY.md section 8)"
         self._init_common(key, observation_dim, n_actions, features, layer_norm, architecture_type, learning_rate, gamma,
-                          update_horizon, data_to_update, target_update_frequency, adam_eps, dtype, params)
+                          update_horizon, data_to_update, target_update_frequency, adam_eps, dtype, params, batch_norm=batch_norm)
 
     def update_online_params(self, step, replay_buffer):
         if step % self.data_to_update == 0:
@@ -157,5 +166,7 @@ class TFDQN(_OneHead):
 
     def learn_on_batch(self, params, optimizer_state, samples):
         grads, loss = self.grads(params, samples)
+        if self.batch_norm:  # params["batch_stats"] = batch_stats["batch_stats"] (tfdqn.py:62-63)
+            self.batch_stats = {m: {n: t.detach().to(self.dtype) for n, t in l.items()} for m, l in self._new_stats.items()}
         new_p, new_state = self._adam(params, optimizer_state, grads)
         return new_p, new_state, loss

@@ -212,3 +212,30 @@ def test_agent_with_batchnorm_trains_acts_and_exports_like_the_oracle_agent():
     q_own = agent.q_values(agent.params, state)
     for head in range(K):
         assert agent.best_action(agent.params, state, key=head) == int(np.argmax(q_own[1 + head]))
+
+
+def test_tfdqn_with_batchnorm_matches_the_oracle():
+    """TFDQN(batch_norm=True) (tfdqn.py:56-80): one shared-parameter head regressed on its own stop-gradient target, training-mode
+    BatchNorm over concat(state, next_state); a learn step's loss, running averages and parameters against the oracle's."""
+    from oracle.dqn import TFDQN as Oracle
+    from slimdqn.networks.tfdqn import TFDQN
+
+    A, B, feats = 4, 8, [8, 16, 16, 32]
+    agent = TFDQN(0, (84, 84, 4), A, feats, True, True, "cnn", 1e-3, 0.99, 1, 1, 6, adam_eps=1.5e-4, batch_size=B)
+    model = agent.get_model()
+    assert set(model) == {"params", "batch_stats"}
+    oracle = Oracle(0, (84, 84, 4), A, feats, True, True, "cnn", 1e-3, 0.99, 1, 1, 6, adam_eps=1.5e-4, params=model["params"])
+    _frames, _ids, _a, _r, _t, ref = make_frame_batch(B, A, seed=21)
+    o_loss = float(oracle.loss_on_batch(oracle.params, ref)[0])
+    oracle.params, oracle.optimizer_state, o_loss2 = oracle.learn_on_batch(oracle.params, oracle.optimizer_state, ref)
+    _, _, loss = agent.learn_on_batch(agent.params, agent.optimizer_state, ref)
+    got = float(loss.cpu().numpy().reshape(-1)[0])
+    assert abs(got - o_loss) < 1e-3 * max(1.0, abs(o_loss)) and abs(o_loss - o_loss2) < 1e-12
+    after = agent.get_model()
+    for m, l in oracle.batch_stats.items():
+        for n, t in l.items():
+            assert np.abs(after["batch_stats"][m][n] - t.numpy()).max() < 2e-5 * max(1.0, float(t.abs().max())), (m, n)
+    exp = oracle.get_model()["params"]
+    for m in exp:
+        for n in exp[m]:
+            assert np.abs(after["params"][m][n] - exp[m][n]).max() < 2.001e-3, (m, n)  # one Adam step of lr = 1e-3
