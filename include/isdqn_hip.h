@@ -163,7 +163,8 @@ typedef struct isdqn_net_config {
                                            * the batch statistics of concat(state, next_state) (isdqn.py:95), which couples the two
                                            * halves: the backward then runs over all 2B rows (csrc/batchnorm.h, generic engine,
                                            * one stream).  forward / best_action(s) use the running averages (isdqn.py:130).
-                                           * cnn and fc only; the *_target (DQN) and grad_on_batch / analysis entry points
+                                           * impala: also behind the ReLU of every residual block (dqn.py:29-30, module
+                                           * names "Stack_s/BatchNorm_b").  The *_target (DQN) and grad_on_batch / analysis entry points
                                            * return ISDQN_ERR_UNSUPPORTED with it (the reference's DQN cannot run with it either:
                                            * dqn.py:86 applies the network without a mutable batch_stats collection).          */
 } isdqn_net_config;

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void bn_zero_kernel(float* __restrict__ p, int
 }
 
 // -------------------------------------------------------------------------------------------------------------------------------------
+static inline bool cfg_is_cnn(const Plan& P) { return P.L[0].kind == 0; }
 static inline const BnSite* bn_site_of(const Plan& P, int layer) {
     for (int s = 0; s < P.n_bn; ++s)
         if (P.bns[s].layer == layer) return &P.bns[s];
@@ -289,7 +290,7 @@ static int bn_forward(const Plan& P, bool x3, const float* params, const NetInpu
                       hipStream_t st) {
     const float* wmir = ws + P.wsplit_off;
     const float* prev = nullptr;
-    if (const BnSite* b0 = bn_site_of(P, -1)) {  // cnn: BatchNorm(x / 255) (dqn.py:51-53)
+    if (const BnSite* b0 = cfg_is_cnn(P) ? bn_site_of(P, -1) : nullptr) {  // cnn: BatchNorm(x / 255) (dqn.py:51-53)
         const Layer& l0 = P.L[0];
         const int hw = l0.hin * l0.win;
         FrameSrc fs{in.frames, in.frame_stride, in.frame_ids, l0.cin, in.paired_B, l0.hin, l0.win, in.id_pitch, in.id_off};
@@ -303,7 +304,9 @@ static int bn_forward(const Plan& P, bool x3, const float* params, const NetInpu
         float* act = l.is_head ? q_out : ws + l.act_off;
         float* z = l.is_head ? nullptr : ws + l.z_off;
         int rc;
-        if (l.kind == 0)
+        if (l.kind == 2)  // impala torso: its own sites inside (impala.h)
+            rc = impala_forward(P, x3, params, wmir, in, n_img, z_img, ws, st, running ? 2 : 1);
+        else if (l.kind == 0)
             rc = conv_fwd(l, x3, params, wmir, in, prev, n_img, z_img, act, z, st);
         else
             rc = dense_fwd(l, x3, params, wmir, in, prev, n_img, l.is_head ? 0 : z_img, ws + P.slab_off, act, z, st);
@@ -378,7 +381,7 @@ static int bn_learn_or_loss(const isdqn_net_config* cfg, const Plan& P, float* p
     int dz_ld = P.nha_p;
     for (int i = P.n_layers - 1; i >= 0; --i) {
         const Layer& l = P.L[i];
-        const BnSite* below = bn_site_of(P, i - 1);  // the site this layer reads (i == 0: the input site of the cnn, none for fc)
+        const BnSite* below = (i > 0 || l.kind == 0) ? bn_site_of(P, i - 1) : nullptr;  // the site this layer reads (i == 0: the cnn's input site)
         const float* act_in = below ? ws + below->out_off : nullptr;
         if (!l.is_head) {
             // `da` holds the gradient w.r.t. this layer's BatchNorm output (left by layer i + 1's data gradient)
@@ -387,7 +390,7 @@ static int bn_learn_or_loss(const isdqn_net_config* cfg, const Plan& P, float* p
             if (rc) return rc;
             entry(site->scale_off, site->G_p, ws + site->s2_off, 1, 0);
             entry(site->bias_off, site->G_p, ws + site->s1_off, 1, 0);
-            const int rows = l.kind == 0 ? Bb * l.npix : Bb;
+            const int rows = l.kind != 1 ? Bb * l.npix : Bb;
             int nb = 0;
             rc = ln_bwd(l, params, da, ws + l.z_off, rows, ws + l.dz_off, ws + l.part_off, &nb, st);
             if (rc) return rc;
@@ -395,9 +398,14 @@ static int bn_learn_or_loss(const isdqn_net_config* cfg, const Plan& P, float* p
                 entry(l.g_off, l.out_p, ws + l.part_off, nb, 3 * (int64_t)l.out_p);
                 entry(l.be_off, l.out_p, ws + l.part_off + l.out_p, nb, 3 * (int64_t)l.out_p);
             }
-            entry(l.b_off, l.out_p, ws + l.part_off + 2 * l.out_p, nb, 3 * (int64_t)l.out_p);
+            if (l.b_off >= 0) entry(l.b_off, l.out_p, ws + l.part_off + 2 * l.out_p, nb, 3 * (int64_t)l.out_p);  // (the impala torso has no bias of its own)
             dz_cur = ws + l.dz_off;
             dz_ld = l.out_p;
+            if (l.kind == 2) {  // the impala torso: its own backward and optimizer launches over the 2B rows
+                rc = impala_backward(P, cfg, x3, params, adam_m, adam_v, wmir, ws, Bb, grad_out, update, st, true);
+                if (rc) return rc;
+                continue;
+            }
         } else {
             entry(l.b_off, l.out_p, ws + P.dbh_off, 1, 0);
         }

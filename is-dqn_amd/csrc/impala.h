@@ -9,7 +9,8 @@
 // accumulation -- the arithmetic of the cnn torso), everything between them as plain row-wise kernels on fp32 tensors
 // [image][y][x][c padded to 8].  The residual stream stays fp32; S8 copies are written where an MFMA problem consumes a tensor.
 // The torso is one pseudo-layer of the plan (net_plan.h): the dense tail, the head chain and the fused dense data gradient see
-// the geometry of a conv layer's output.  BatchNorm variants are not built.
+// the geometry of a conv layer's output.  BatchNorm (dqn.py:29-30, 78-79): the sites of batchnorm.h between the kernels below
+// (`bn_mode`: 1 batch statistics, 2 running averages), the backward then over all 2B rows.
 //
 // Included by net_kernels.hip inside namespace isdqn, after the conv launchers and the Adam kernel.
 #pragma once
@@ -310,17 +311,24 @@ static int imp_conv_fwd(const Layer& c, bool x3, const float* params, const floa
 
 // frames -> relu(LN(residual stream behind Stack_2)) as the pseudo-layer's S8 activation (+ its fp32 pre-LayerNorm rows for the backward)
 static int impala_forward(const Plan& P, bool x3, const float* params, const float* wmir, const NetInput& in, int n_img, int z_img,
-                          float* ws, hipStream_t st) {
+                          float* ws, hipStream_t st, int bn_mode) {
     const Layer& L0 = P.L[0];
     for (int s = 0; s < IMP_STACKS; ++s) {
         const ImpalaStack& S = P.imp[s];
         const int64_t big = (int64_t)n_img * S.H * S.W, small = (int64_t)n_img * S.Hp * S.Wp;
+        const float* x_in = ws + S.xin_off;
         if (s == 0) {
             FrameSrc fs{in.frames, in.frame_stride, in.frame_ids, S.cin, in.paired_B, S.H, S.W, in.id_pitch, in.id_off};
-            hipLaunchKernelGGL(imp_frames_kernel, dim3((unsigned)((big + 255) / 256)), dim3(256), 0, st, fs, n_img, S.H * S.W, ws + S.xin_off);
+            hipLaunchKernelGGL(imp_frames_kernel, dim3((unsigned)((big + 255) / 256)), dim3(256), 0, st, fs, n_img, S.H * S.W,
+                               ws + (bn_mode ? P.x0_off : S.xin_off));
             ISDQN_HIP_CHECK(hipGetLastError());
+            if (bn_mode) {  // BatchNorm(x / 255) (dqn.py:78-79)
+                const BnSite* b0 = bn_site_of(P, -1);
+                if (int rc0 = bn_site_forward(*b0, params, ws, n_img, bn_mode == 2, st)) return rc0;
+                x_in = ws + b0->out_off;
+            }
         }
-        int rc = imp_conv_fwd(S.conv[0], x3, params, wmir, ws + S.xin_off, n_img, nullptr, ws + S.z0_off, st);
+        int rc = imp_conv_fwd(S.conv[0], x3, params, wmir, x_in, n_img, nullptr, ws + S.z0_off, st);
         if (rc) return rc;
         const int cq = S.C_p / 4;
         hipLaunchKernelGGL(imp_pool_fwd_kernel, dim3((unsigned)((small * cq + 255) / 256)), dim3(256), 0, st, ws + S.z0_off, n_img, S.H, S.W, S.Hp,
@@ -332,7 +340,13 @@ static int impala_forward(const Plan& P, bool x3, const float* params, const flo
             hipLaunchKernelGGL(imp_lnrelu_fwd_kernel, dim3(imp_blocks(small)), dim3(256), 0, st, ws + S.r_off[b], g, be, small, S.C, S.C_p,
                                ws + S.a1_off[b]);
             ISDQN_HIP_CHECK(hipGetLastError());
-            rc = imp_conv_fwd(S.conv[1 + 2 * b], x3, params, wmir, ws + S.a1_off[b], n_img, ws + S.a2_off[b], nullptr, st);  // act = relu(conv)
+            const float* a1 = ws + S.a1_off[b];
+            if (bn_mode) {  // dqn.py:29-30
+                const BnSite* bs = bn_site_of(P, -2 - (2 * s + b));
+                if ((rc = bn_site_forward(*bs, params, ws, n_img, bn_mode == 2, st))) return rc;
+                a1 = ws + bs->out_off;
+            }
+            rc = imp_conv_fwd(S.conv[1 + 2 * b], x3, params, wmir, a1, n_img, ws + S.a2_off[b], nullptr, st);  // act = relu(conv)
             if (rc) return rc;
             rc = imp_conv_fwd(S.conv[2 + 2 * b], x3, params, wmir, ws + S.a2_off[b], n_img, nullptr, ws + S.zt_off, st);
             if (rc) return rc;
@@ -355,8 +369,10 @@ static int impala_forward(const Plan& P, bool x3, const float* params, const flo
 
 // backward through the torso for the first B images, from dz of the pseudo-layer (S8, gradient w.r.t. the residual stream behind
 // Stack_2); every inner tensor's gradient goes straight into its own optimizer launch (slab sums inside adam_kernel)
+// (`bn`: BatchNorm networks -- B is then the 2B rows of concat(state, next_state), and the first Stack's convolution gets a data
+// gradient too: the input site has a scale and a bias)
 static int impala_backward(const Plan& P, const isdqn_net_config* cfg, bool x3, float* params, float* adam_m, float* adam_v, const float* wmir,
-                           float* ws, int B, float* grad_out, bool update, hipStream_t st) {
+                           float* ws, int B, float* grad_out, bool update, hipStream_t st, bool bn = false) {
     const Layer& L0 = P.L[0];
     std::vector<AdamEntry> entries;
     auto entry = [&](int64_t p_off, int64_t size, const float* g, int n_slabs, int64_t stride) {
@@ -409,10 +425,17 @@ static int impala_backward(const Plan& P, const isdqn_net_config* cfg, bool x3, 
             if (rc) return rc;
             rc = to_s8(da, ws + S.a2_off[b], small, S.C_p, dzs, ws + S.bpart_off[1 + 2 * b], c1.b_off);  // through relu(conv1)
             if (rc) return rc;
-            rc = wgrad(c1, ws + S.a1_off[b], dzs);
+            const BnSite* bs = bn ? bn_site_of(P, -2 - (2 * s + b)) : nullptr;
+            rc = wgrad(c1, bs ? ws + bs->out_off : ws + S.a1_off[b], dzs);
             if (rc) return rc;
             rc = dgrad(c1, dzs, da);
             if (rc) return rc;
+            if (bs) {  // through the block's BatchNorm: da becomes the gradient w.r.t. relu([LN](r)) in place
+                rc = bn_site_backward(*bs, params, ws, da, B, true, st);
+                if (rc) return rc;
+                entry(bs->scale_off, bs->G_p, ws + bs->s2_off, 1, 0);
+                entry(bs->bias_off, bs->G_p, ws + bs->s1_off, 1, 0);
+            }
             const float* g = S.ln_g[b] >= 0 ? params + S.ln_g[b] : nullptr;
             const float* be = S.ln_b[b] >= 0 ? params + S.ln_b[b] : nullptr;
             const int nb = imp_blocks(small);
@@ -430,12 +453,19 @@ static int impala_backward(const Plan& P, const isdqn_net_config* cfg, bool x3, 
         ISDQN_HIP_CHECK(hipGetLastError());
         rc = to_s8(ws + S.dz0_off, nullptr, big, S.C_p, dzs, ws + S.bpart_off[0], S.conv[0].b_off);
         if (rc) return rc;
-        rc = wgrad(S.conv[0], ws + S.xin_off, dzs);
+        const BnSite* b0 = (bn && s == 0) ? bn_site_of(P, -1) : nullptr;
+        rc = wgrad(S.conv[0], b0 ? ws + b0->out_off : ws + S.xin_off, dzs);
         if (rc) return rc;
-        if (s > 0) {
+        if (s > 0 || b0) {
             rc = dgrad(S.conv[0], dzs, da);  // [B][H][W][cin_p] = the gradient of the previous Stack's residual stream
             if (rc) return rc;
             dr = da;
+        }
+        if (b0) {  // scale / bias of the input site (sums only)
+            rc = bn_site_backward(*b0, params, ws, da, B, false, st);
+            if (rc) return rc;
+            entry(b0->scale_off, b0->G_p, ws + b0->s2_off, 1, 0);
+            entry(b0->bias_off, b0->G_p, ws + b0->s1_off, 1, 0);
         }
     }
     // the optimizer over the torso's tensors (slab / partial sums inside the kernel), a table at a time

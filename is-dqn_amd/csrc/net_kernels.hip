@@ -1399,7 +1399,7 @@ static int dense_fwd(const Layer& l, bool x3, const float* params, const float* 
 }
 
 static int impala_forward(const Plan& P, bool x3, const float* params, const float* wmir, const NetInput& in, int n_img, int z_img,
-                          float* ws, hipStream_t st);  // impala.h
+                          float* ws, hipStream_t st, int bn_mode = 0);  // impala.h
 
 static int bn_forward(const Plan& P, bool x3, const float* params, const NetInput& in, int n_img, int z_img, float* ws, float* q_out, bool running,
                       hipStream_t st);  // batchnorm.h
@@ -1693,6 +1693,10 @@ static int conv_wgrad_slabs(const Layer& l, int n_img) {
     return ceil_div(ksteps, sps);
 }
 
+// (batchnorm.h, used by the impala torso's BatchNorm sites)
+static inline const BnSite* bn_site_of(const Plan& P, int layer);
+static int bn_site_forward(const BnSite& b, const float* params, float* ws, int rows, bool running, hipStream_t st);
+static int bn_site_backward(const BnSite& b, const float* params, float* ws, float* dy, int rows, bool apply, hipStream_t st);
 #include "impala.h"
 #include "batchnorm.h"
 
@@ -1761,7 +1765,10 @@ extern "C" int isdqn_net_param_layout(const isdqn_net_config* cfg, int64_t* n_pa
     }
     for (int s = 0; s < P.n_bn; ++s) {  // BatchNorm_s: scale / bias ("params"), mean / var ("batch_stats")
         const BnSite& b = P.bns[s];
-        const int H = b.layer < 0 ? P.L[0].hin : P.L[b.layer].hout, W = b.layer < 0 ? P.L[0].win : P.L[b.layer].wout;
+        int H, W;
+        if (b.layer == -1) { H = P.L[0].hin; W = P.L[0].win; }
+        else if (b.layer <= -2) { H = P.imp[(-2 - b.layer) / 2].Hp; W = P.imp[(-2 - b.layer) / 2].Wp; }
+        else { H = P.L[b.layer].hout; W = P.L[b.layer].wout; }
         const int64_t offs[4] = {b.scale_off, b.bias_off, b.mean_off, b.var_off};
         static const char* const leaves[4] = {"scale", "bias", "mean", "var"};
         for (int k = 0; k < 4; ++k) {

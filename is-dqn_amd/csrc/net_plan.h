@@ -65,13 +65,14 @@ struct ImpalaStack {
 // normalises is [rows][P][Cp] in the internal layout.  `spatial` (BatchNorm(axis=(1, 2)) on an image tensor): one statistic per pixel
 // position p over the batch AND the C channels; otherwise (2-D input) one per internal column p * Cp + c over the batch.
 struct BnSite {
-    int layer;    // hidden layer whose post-ReLU activation it normalises (-1: the network input x / 255)
+    int layer;    // hidden layer whose post-ReLU activation it normalises (-1: the network input x / 255; -2 - (2 s + b): residual
+                  // block b of impala Stack s, behind its ReLU -- dqn.py:29-30)
     int spatial;
     int P, C, Cp; // positions, channels, padded channels
     int G, G_p;   // statistic groups (spatial: P; feature: P * Cp internal columns), padded to 8
     int64_t scale_off, bias_off, mean_off, var_off;  // parameter buffer (floats): scale / bias are optimised, mean / var are the running averages
     int64_t in_off, out_off, bmean_off, bvar_off, s1_off, s2_off;  // workspace (floats): S8 input / output rows, batch statistics, backward sums
-    char name[16];
+    char name[32];  // Flax module path ("BatchNorm_3", "Stack_1/BatchNorm_0")
 };
 
 struct Plan {
@@ -83,7 +84,7 @@ struct Plan {
     int Bb;   // rows the backward runs over: B (the next-state half has a zero cotangent, isdqn.py:99) -- N2 with BatchNorm, whose
               // batch statistics carry the gradient into the next-state rows
     int n_bn;
-    BnSite bns[MAX_LAYERS + 1];
+    BnSite bns[MAX_LAYERS + 1 + 2 * IMP_STACKS];
     int64_t x0_off;  // BatchNorm, cnn: the network input frames / 255 as S8 [N2][h * w][8]; fc: concat(state, next_state) fp32 [N2][obs]
     int n_heads, n_actions, nha, nha_p;
     // K regressed heads; head k + oh (online rows) is regressed on head k (next-state rows).  iS-DQN: n_heads = 1 + K,
@@ -118,7 +119,6 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
                   "bad precision");
     ISDQN_REQUIRE(cfg->huber_delta >= 0.f, ISDQN_ERR_ARG, "huber_delta must be >= 0 (0 = squared error)");
     ISDQN_REQUIRE(cfg->batch_norm == 0 || cfg->batch_norm == 1, ISDQN_ERR_ARG, "batch_norm must be 0 or 1");
-    ISDQN_REQUIRE(!cfg->batch_norm || cfg->arch != ISDQN_ARCH_IMPALA, ISDQN_ERR_UNSUPPORTED, "BatchNorm inside the impala Stacks is not built (cnn and fc are)");
     P.regions.clear();
     P.B = cfg->batch_size;
     P.N2 = 2 * P.B;
@@ -157,7 +157,8 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
 
     // BatchNorm_i in call order (Flax auto-names per class): scale and bias join the optimised parameters here, the running
     // averages are placed behind all of them (below)
-    auto add_bn = [&](int layer, int spatial, int Pn, int C, int Cp) {
+    int n_bn_top = 0;  // (Flax counts BatchNorm modules per parent: the Stacks' own ones are "Stack_s/BatchNorm_b")
+    auto add_bn = [&](int layer, int spatial, int Pn, int C, int Cp, const char* name = nullptr) {
         BnSite& b = P.bns[P.n_bn];
         memset(&b, 0, sizeof(b));
         b.layer = layer; b.spatial = spatial; b.P = Pn; b.C = C; b.Cp = Cp;
@@ -165,7 +166,8 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
         b.G_p = round_up(b.G, 8);
         b.scale_off = poff; poff += b.G_p;
         b.bias_off = poff; poff += b.G_p;
-        snprintf(b.name, sizeof(b.name), "BatchNorm_%d", P.n_bn);
+        if (name) snprintf(b.name, sizeof(b.name), "%s", name);
+        else snprintf(b.name, sizeof(b.name), "BatchNorm_%d", n_bn_top++);
         ++P.n_bn;
     };
 
@@ -213,6 +215,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
     } else if (cfg->arch == ISDQN_ARCH_IMPALA) {
         ISDQN_REQUIRE(cfg->obs_h >= 8 && cfg->obs_w >= 8 && cfg->obs_c >= 1 && cfg->obs_c <= 8, ISDQN_ERR_ARG, "bad observation shape");
         int h = cfg->obs_h, w = cfg->obs_w, c = cfg->obs_c, c_p = 8;
+        if (P.bn) add_bn(-1, 1, h * w, c, c_p);  // dqn.py:78-79
         auto conv3 = [&](Layer& l, int hh, int ww, int cin, int cin_p, int cout, const char* nm) {
             memset(&l, 0, sizeof(l));
             l.kind = 0; l.has_relu = 0; l.is_u8 = 0;
@@ -244,7 +247,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
             same_padding(w, 3, 2, S.Wp, pw);
             ISDQN_REQUIRE(pw == S.pool_pad, ISDQN_ERR_UNSUPPORTED, "non-square observations are not supported by the impala torso");
             // parameters in Flax's order inside a Stack: Conv_0, then per block LayerNorm_b, Conv_{1+2b}, Conv_{2+2b} (dqn.py:17-34)
-            char nm[16];
+            char nm[32];
             snprintf(nm, sizeof(nm), "Conv_0");
             conv3(S.conv[0], h, w, c, c_p, S.C, nm);
             for (int b = 0; b < 2; ++b) {
@@ -253,6 +256,10 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
                     S.ln_b[b] = poff; poff += S.C_p;
                 } else {
                     S.ln_g[b] = S.ln_b[b] = -1;
+                }
+                if (P.bn) {  // dqn.py:29-30: BatchNorm(axis=(1, 2)) behind the block's ReLU
+                    snprintf(nm, sizeof(nm), "Stack_%d/BatchNorm_%d", s, b);
+                    add_bn(-2 - (2 * s + b), 1, S.Hp * S.Wp, S.C, S.C_p, nm);
                 }
                 for (int k = 1 + 2 * b; k <= 2 + 2 * b; ++k) {
                     snprintf(nm, sizeof(nm), "Conv_%d", k);
@@ -281,6 +288,7 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
         } else {
             l.g_off = l.be_off = -1;
         }
+        if (P.bn) add_bn(nl - 1, 0, l.npix, l.cout, l.cout_p);  // dqn.py:86-88: per feature behind the flatten
         in_elems_p = h * w * c_p;
         in_f = h * w * c;
         in_p = in_elems_p;
@@ -435,15 +443,15 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
                 S.lnpart_off[b] = region(pre + "lnpart" + std::to_string(b), (int64_t)LN_MAX_BLOCKS * 2 * S.C_p);
             }
             S.zt_off = region(pre + "zt", P.N2 * small * S.C_p);
-            S.dr_off = region(pre + "dr", P.B * small * S.C_p);
-            S.da_off = region(pre + "da", P.B * std::max(big * S.cin_p, small * S.C_p));
-            S.dzs_off = region(pre + "dzs", P.B * big * S.C_p);
-            S.dz0_off = region(pre + "dz0", P.B * big * S.C_p);
+            S.dr_off = region(pre + "dr", P.Bb * small * S.C_p);
+            S.da_off = region(pre + "da", P.Bb * std::max(big * S.cin_p, small * S.C_p));
+            S.dzs_off = region(pre + "dzs", P.Bb * big * S.C_p);
+            S.dz0_off = region(pre + "dz0", P.Bb * big * S.C_p);
             for (int k = 0; k < IMP_CONVS; ++k) {
                 Layer& c = S.conv[k];
                 S.bpart_off[k] = region(pre + "bpart" + std::to_string(k), (int64_t)LN_MAX_BLOCKS * S.C_p);
                 int tiles_n = ceil_div(c.K, 64);
-                int ksteps = ceil_div(P.B * c.npix, 32);
+                int ksteps = ceil_div(P.Bb * c.npix, 32);
                 int sp = 256 / tiles_n;
                 if (sp < 1) sp = 1;
                 if (sp > ksteps) sp = ksteps;
@@ -456,9 +464,12 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
         BnSite& b = P.bns[s];
         const std::string pre = std::string("bn/") + b.name + "/";
         const int64_t width = (int64_t)b.P * b.Cp;
-        if (b.layer < 0) {
+        if (b.layer == -1) {
             P.x0_off = region("bn/x0", (int64_t)P.N2 * width);
             b.in_off = P.x0_off;
+        } else if (b.layer <= -2) {  // impala block: the S8 output of its [LayerNorm +] ReLU
+            const int sb = -2 - b.layer;
+            b.in_off = P.imp[sb / 2].a1_off[sb % 2];
         } else {
             b.in_off = P.L[b.layer].act_off;
         }

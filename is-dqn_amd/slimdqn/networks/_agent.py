@@ -16,9 +16,8 @@ class DeviceParams:
         self._engine = engine
         self.tensor = tensor
 
-    def to_flax(self):
-        """The reference's ``params["params"]`` pytree; nested modules (the impala Stacks) as nested dicts like Flax's."""
-        flat = self._engine.export_flax(self.tensor)
+    @staticmethod
+    def _nest(flat):
         out = {}
         for mod, leaves in flat.items():
             node = out
@@ -27,9 +26,14 @@ class DeviceParams:
             node.update(leaves)
         return out
 
+    def to_flax(self):
+        """The reference's ``params["params"]`` pytree; nested modules (the impala Stacks) as nested dicts like Flax's."""
+        return self._nest(self._engine.export_flax(self.tensor))
+
     def batch_stats(self):
-        """Flax's second collection of a BatchNorm network (isdqn.py:87-88): {"BatchNorm_i": {"mean", "var"}}."""
-        return self._engine.export_batch_stats(self.tensor)
+        """Flax's second collection of a BatchNorm network (isdqn.py:87-88): {"BatchNorm_i": {"mean", "var"}} (the impala Stacks'
+        own modules nested: {"Stack_0": {"BatchNorm_1": ...}})."""
+        return self._nest(self._engine.export_batch_stats(self.tensor))
 
     def __getitem__(self, key):
         if key == "batch_stats" and self._engine.batch_norm:
@@ -115,12 +119,15 @@ class EngineAgent:
             return None
         if isinstance(params, DeviceParams):
             return params.tensor
-        tree = params["params"] if "params" in params else params
-        if any(k.startswith("Stack_") and "/" not in k for k in tree):  # Flax nesting -> the engine's flattened "Stack_0/Conv_1" keys
-            tree = {**{f"{k}/{m}": v for k, sub in tree.items() if k.startswith("Stack_") for m, v in sub.items()},
+        def flatten(tree):  # Flax nesting -> the engine's flattened "Stack_0/Conv_1" keys
+            if tree is None or not any(k.startswith("Stack_") and "/" not in k for k in tree):
+                return tree
+            return {**{f"{k}/{m}": v for k, sub in tree.items() if k.startswith("Stack_") for m, v in sub.items()},
                     **{k: v for k, v in tree.items() if not k.startswith("Stack_")}}
+
+        tree = flatten(params["params"] if "params" in params else params)
         t = torch.empty_like(self._engine.params)
-        self._engine.import_flax(tree, target=t, batch_stats=params.get("batch_stats") if "params" in params else None)
+        self._engine.import_flax(tree, target=t, batch_stats=flatten(params.get("batch_stats")) if "params" in params else None)
         return t
 
     # ------------------------------------------------------------------ batches

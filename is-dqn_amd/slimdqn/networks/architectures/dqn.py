@@ -9,7 +9,7 @@
            [LayerNorm] -> ReLU -> flatten, then the same Dense tail                                  (:7-36, :75-88; csrc/impala.h)
   * batch_norm: flax.linen.BatchNorm behind the input scaling and behind every hidden ReLU -- ``axis=(1, 2)`` on image tensors
            (one statistic per pixel position, over batch and channels), per feature behind the flatten and the Dense layers
-           (:52-53, 59-60, 66-67, 73-74, 100-101; csrc/batchnorm.h).  cnn and fc; the impala Stacks with BatchNorm raise.
+           (:52-53, 59-60, 66-67, 73-74, 100-101), and inside every residual block of the impala Stacks (:29-30; csrc/batchnorm.h).
 """
 from typing import Sequence
 
@@ -19,8 +19,6 @@ class DQNNet:
                  batch_norm: bool = False):
         if architecture_type not in ("cnn", "impala", "fc"):
             raise NotImplementedError(f"architecture_type={architecture_type!r}: 'cnn', 'impala' or 'fc'")
-        if batch_norm and architecture_type == "impala":
-            raise NotImplementedError("BatchNorm inside the impala Stacks is not built (cnn and fc are)")
         if architecture_type in ("cnn", "impala") and len(features) < 3:
             raise ValueError("cnn needs at least the three convolution widths")
         self.features = [int(f) for f in features]

@@ -26,7 +26,7 @@ documented behaviour of those versions at the reference's own call sites:
         one (scale, bias) per pixel position (h, w) and reduces over the batch AND the channels; the default axis=-1 on the
         flattened / dense (N, F) tensors is per feature.  y = (x - mean) * (rsqrt(var + eps) * scale) + bias.  Training-mode
         calls (apply_fn with mutable batch_stats, isdqn.py:40, 95) use the batch statistics and move the running averages
-        ra = 0.99 ra + 0.01 batch; best_action (isdqn.py:130) passes use_running_average=True.  cnn and fc only here.
+        ra = 0.99 ra + 0.01 batch; best_action (isdqn.py:130) passes use_running_average=True.
   * iSDQN.loss_on_batch / compute_target ....... slimdqn/networks/isdqn.py:92-109
   * iSDQN.learn_on_batch (grad + optax.adam) ... isdqn.py:82-90, 46
         adam: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; t += 1 ;
@@ -156,23 +156,29 @@ def init_params(
         dense_feats = [int(f) for f in features[3:]]
         init = lambda shape: xavier(shape, shape[0], shape[1])
     elif architecture_type == "impala":
-        assert not batch_norm, "BatchNorm inside the impala Stacks is not restated"
         # dqn.py:75-88 + Stack (dqn.py:7-36): three stacks of conv3x3 -> max_pool 3x3 / 2 SAME -> two residual blocks
         # ([LayerNorm] -> relu -> conv3x3 -> relu -> conv3x3 -> + input); modules are auto-named per class INSIDE each Stack
         # (Conv_0 .. Conv_4, LayerNorm_0 .. LayerNorm_1), the Stacks Stack_0 .. Stack_2, and the LayerNorm behind the last stack
         # is the top level's LayerNorm_0.  The stack's first conv takes xavier_uniform, the block convs Flax's default
         # lecun_normal (dqn.py:17-21 passes kernel_init only there).  Nested modules are flattened to "Stack_s/Conv_k" keys.
+        # batch_norm: BatchNorm(axis=(1, 2)) on x / 255 (:78-79, top-level BatchNorm_0), inside every residual block behind the
+        # ReLU (:29-30, "Stack_s/BatchNorm_b", one statistic per pooled pixel position) and per feature behind the flatten (:86-88)
         h, w, c = observation_dim
+        add_bn((h, w))
         for s_idx in range(3):
             cout = int(features[s_idx])
             params[f"Stack_{s_idx}/Conv_0"] = {"kernel": xavier((3, 3, c, cout), 9 * c, 9 * cout), "bias": np.zeros(cout, np.float32)}
+            hp, wp = same_padding(h, 3, 2)[0], same_padding(w, 3, 2)[0]
             for b in range(2):
                 if layer_norm:
                     params[f"Stack_{s_idx}/LayerNorm_{b}"] = {"scale": np.ones(cout, np.float32), "bias": np.zeros(cout, np.float32)}
+                if batch_norm:
+                    params[f"Stack_{s_idx}/BatchNorm_{b}"] = {"scale": np.ones((hp, wp), np.float32), "bias": np.zeros((hp, wp), np.float32)}
                 for k in (1 + 2 * b, 2 + 2 * b):
                     params[f"Stack_{s_idx}/Conv_{k}"] = {"kernel": lecun((3, 3, cout, cout), 9 * cout), "bias": np.zeros(cout, np.float32)}
-            h, w, c = same_padding(h, 3, 2)[0], same_padding(w, 3, 2)[0], cout
+            h, w, c = hp, wp, cout
         add_ln(c)
+        add_bn((h * w * c,))
         width = h * w * c
         dense_feats = [int(f) for f in features[3:]]
         init = lambda shape: xavier(shape, shape[0], shape[1])
@@ -199,7 +205,7 @@ def init_params(
 def init_batch_stats(params) -> Dict[str, Dict[str, np.ndarray]]:
     """Flax's ``batch_stats`` collection at initialisation: mean 0, var 1 with the shape of each BatchNorm_i's scale."""
     return {m: {"mean": np.zeros_like(np.asarray(l["scale"]), dtype=np.float32), "var": np.ones_like(np.asarray(l["scale"]), dtype=np.float32)}
-            for m, l in params.items() if m.startswith("BatchNorm_")}
+            for m, l in params.items() if m.rsplit("/", 1)[-1].startswith("BatchNorm_")}
 
 
 # ----------------------------------------------------------------------------- torch forward
@@ -248,8 +254,9 @@ def _max_pool_same(x_nhwc: torch.Tensor, window: int = 3, stride: int = 2) -> to
     return F.max_pool2d(x, window, stride).permute(0, 2, 3, 1)
 
 
-def _impala_stack(params, prefix: str, x: torch.Tensor, layer_norm: bool, capture: dict | None = None) -> torch.Tensor:
-    """Stack.__call__ (dqn.py:14-36) without BatchNorm.  ``capture`` receives the residual stream in front of each block."""
+def _impala_stack(params, prefix: str, x: torch.Tensor, layer_norm: bool, capture: dict | None = None, bn=None) -> torch.Tensor:
+    """Stack.__call__ (dqn.py:14-36).  ``capture`` receives the residual stream in front of each block; ``bn(x, name)`` applies the
+    block's BatchNorm(axis=(1, 2)) behind the ReLU (dqn.py:29-30) when the network has them."""
     p = params[f"{prefix}/Conv_0"]
     x = _conv_same(x, p["kernel"], p["bias"], 1)
     x = _max_pool_same(x)
@@ -261,6 +268,8 @@ def _impala_stack(params, prefix: str, x: torch.Tensor, layer_norm: bool, captur
             q = params[f"{prefix}/LayerNorm_{b}"]
             x = _layer_norm(x, q["scale"], q["bias"])
         x = torch.relu(x)
+        if bn is not None:
+            x = bn(x, f"{prefix}/BatchNorm_{b}")
         p = params[f"{prefix}/Conv_{1 + 2 * b}"]
         x = _conv_same(x, p["kernel"], p["bias"], 1)
         x = torch.relu(x)
@@ -312,17 +321,17 @@ def forward(params, x, features, architecture_type: str, layer_norm: bool, captu
         x = bn(x.reshape(x.shape[0], -1), False)
         start = 3
     elif architecture_type == "impala":  # dqn.py:75-88
-        assert not batch_norm
-        x = x / 255.0
+        x = bn(x / 255.0, True)
+        inner = (lambda t, name: _batch_norm(t, params[name], batch_stats, use_running_average, True, new_stats, name)) if batch_norm else None
         for s_idx in range(3):
-            x = _impala_stack(params, f"Stack_{s_idx}", x, layer_norm, capture)
+            x = _impala_stack(params, f"Stack_{s_idx}", x, layer_norm, capture, bn=inner)
             if capture is not None:
                 capture[f"Stack_{s_idx}"] = x
         if layer_norm:
             q = params[f"LayerNorm_{n_ln}"]
             x = _layer_norm(x, q["scale"], q["bias"])
             n_ln += 1
-        x = torch.relu(x).reshape(x.shape[0], -1)
+        x = bn(torch.relu(x).reshape(x.shape[0], -1), False)
         start = 3
     else:
         x = x.reshape(x.shape[0], -1)

@@ -28,7 +28,10 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
 
 
-def _check_step(oracle, eng, batch, ref, n_steps=3, grad_tol=3e-3):
+def _check_step(oracle, eng, batch, ref, n_steps=3, grad_tol=3e-3, later_loss_tol=1e-3, trajectory=True):
+    """``trajectory=False`` (the impala torso: max-pool winners and ReLU masks of 2B small images -- a few decisions differ between two
+    fp32-class forwards, and Adam moves an entry whose gradient changes sign by a full lr either way): the first step's update is
+    checked against Adam applied to the path's OWN gradient instead of against the oracle's parameters, later losses loosely."""
     K = oracle.n_bellman_iterations
     # ---- training-mode pass: q-values, targets, losses (batch statistics of the 2B rows) ----
     o_q, o_t, o_td = oracle.loss_terms(oracle.params, ref)
@@ -48,14 +51,25 @@ def _check_step(oracle, eng, batch, ref, n_steps=3, grad_tol=3e-3):
     for step in range(n_steps):
         o_grads, _ = oracle.grads(p, ref)
         p, st, o_losses = oracle.learn_on_batch(p, st, ref)
+        p0 = eng.params.clone()
         losses = eng.learn_on_batch(batch, grad_out=grad).cpu().numpy()
-        assert np.abs(losses - o_losses).max() < 1e-3 * max(1.0, np.abs(o_losses).max()), f"step {step}"
+        assert np.abs(losses - o_losses).max() < (1e-3 if step == 0 else later_loss_tol) * max(1.0, np.abs(o_losses).max()), f"step {step}"
         if step == 0:
             g = eng.internal_to_flax_grads(grad)
             for mod in o_grads:
                 for leaf in o_grads[mod]:
                     e = _rel(g[mod][leaf], o_grads[mod][leaf].numpy())
                     assert e < grad_tol, f"grad {mod}/{leaf}: rel err {e}"
+            num = sum(float(np.sum((np.asarray(g[m][n], np.float64) - o_grads[m][n].numpy()) ** 2)) for m in o_grads for n in o_grads[m])
+            den = sum(float(np.sum(o_grads[m][n].numpy().astype(np.float64) ** 2)) for m in o_grads for n in o_grads[m])
+            assert num <= (3 * grad_tol) ** 2 * den, f"whole gradient, Euclidean: {(num / den) ** 0.5}"
+            if not trajectory:  # optax.adam's first step on the path's own gradient: p -= lr * g / (|g| + eps), optimised tensors only
+                want = p0 - eng.cfg.learning_rate * grad / (grad.abs() + eng.cfg.adam_eps)
+                sel = torch.zeros_like(grad, dtype=torch.bool)
+                for info in eng.infos:
+                    if info.kind < 7:
+                        sel[info.offset : info.offset + info.size] = True
+                assert float((eng.params - want)[sel].abs().max()) < 2e-6
             pri = eng.priorities.cpu().numpy()
             exp = np.sqrt(o_td.detach().numpy().mean(1) + 1e-10)
             assert np.abs(pri - exp).max() < 1e-2 * max(1.0, exp.max())
@@ -65,7 +79,10 @@ def _check_step(oracle, eng, batch, ref, n_steps=3, grad_tol=3e-3):
                 d = np.abs(got_stats[m][n] - t.numpy()).max()
                 # (after the first update the two parameter sets differ by Adam's normalised steps: activations, and with
                 # them the batch statistics, drift by ~1e-3)
-                assert d < (2e-5 if step == 0 else 2e-4) * max(1.0, float(t.abs().max())), f"step {step}: running {n} of {m}: {d}"
+                assert d < (2e-5 if step == 0 else max(2e-4, 0.1 * later_loss_tol)) * max(1.0, float(t.abs().max())), f"step {step}: running {n} of {m}: {d}"
+    assert int(eng.adam_count.item()) == n_steps
+    if not trajectory:
+        return
     got = eng.export_flax()
     for mod in p:
         for leaf in p[mod]:
@@ -95,6 +112,35 @@ def test_cnn_batchnorm_matches_the_oracle(cfg):
     assert np.abs(q1.cpu().numpy().reshape(1 + K, A) - q[3]).max() < 1e-5
 
     _check_step(oracle, eng, batch, ref)
+
+
+IMPALA = [
+    pytest.param(((84, 84, 4), (8, 16, 8, 32), 2, 3, 8, True), id="84x84x4-ln-B8"),
+    pytest.param(((36, 36, 2), (16, 8, 16, 24), 3, 4, 9, False), id="36x36x2-noln-B9"),
+]
+
+
+@pytest.mark.parametrize("cfg", IMPALA)
+def test_impala_batchnorm_matches_the_oracle(cfg):
+    """The impala torso with BatchNorm (dqn.py:29-30, 78-79, 86-88): a site on x / 255, one behind the ReLU of each of the six residual
+    blocks ("Stack_s/BatchNorm_b"), one per feature behind the flatten, one behind Dense_0."""
+    obs, feats, K, A, B, ln = cfg
+    # (float64 oracle: per-feature statistics over 16-18 rows divide by small deviations, fp32 noise on the oracle's side would
+    # eat a good part of the 1e-3 bar.  The gradient bound is direct -- no pinned ReLU / max-pool decisions as in
+    # tests/test_gpu_impala.py, whose independent-oracle bound is 15 % Euclidean for the same reason -- hence 5e-2 of each leaf's
+    # largest entry and 15 % of the whole vector; measured: <= 1.6e-2 per leaf)
+    oracle, eng, params = make_pair(feats, K, A, B, arch="impala", obs=obs, layer_norm=ln, seed=6, batch_norm=True, dtype=torch.float64)
+    assert "Stack_2/BatchNorm_1" in params and eng.export_batch_stats()["Stack_0/BatchNorm_0"]["var"].shape == params["Stack_0/BatchNorm_0"]["scale"].shape
+    h, w, stack = obs
+    frames, ids, action, reward, terminal, ref = make_frame_batch(B, A, seed=13, h=h, w=w, stack=stack)
+    batch = device_batch(eng, frames, ids, action, reward, terminal)
+    both = torch.cat((torch.tensor(ref.state), torch.tensor(ref.next_state)))
+    q_run = oracle.apply(oracle.params, both, use_running_average=True).detach().numpy()
+    flat_ids = np.concatenate([ids[:, :stack], ids[:, stack:]], 0).copy()
+    q = eng.forward(frames=batch._keep[0], frame_stride=frames.shape[1], frame_ids=torch.from_numpy(flat_ids).cuda(), n_rows=2 * B)
+    q = q.cpu().numpy().reshape(2 * B, 1 + K, A)
+    assert np.abs(q - q_run).max() < 1e-3 * max(1.0, np.abs(q_run).max()), f"acting forward max err {np.abs(q - q_run).max()}"
+    _check_step(oracle, eng, batch, ref, n_steps=2, grad_tol=5e-2, later_loss_tol=5e-2, trajectory=False)
 
 
 FC = [
@@ -137,13 +183,6 @@ def test_batchnorm_learn_steps_are_bitwise_repeatable():
 
 
 def test_unbuilt_batchnorm_combinations_raise():
-    from slimdqn._engine import QNetEngine
-    from slimdqn.networks.architectures.dqn import DQNNet
-
-    with pytest.raises(NotImplementedError):
-        DQNNet([8, 8, 8, 16], "impala", 6, True, True)
-    with pytest.raises(Exception):
-        QNetEngine((84, 84, 4), 4, 3, (8, 8, 8, 16), "impala", True, 4, batch_norm=True)
     _, eng, _ = make_pair((7, 9, 11, 13), 2, 3, 4, seed=1, batch_norm=True)
     frames, ids, action, reward, terminal, _ref = make_frame_batch(4, 3, seed=2)
     batch = device_batch(eng, frames, ids, action, reward, terminal)
