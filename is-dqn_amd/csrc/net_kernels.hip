@@ -9,6 +9,7 @@
 #include <type_traits>
 #include <vector>
 #include <atomic>
+#include <functional>
 
 #include "conv_img.h"
 #include "conv_ws.h"
@@ -2090,6 +2091,12 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         return plain_big<true, true, true, false, 2>(x3, A, nullptr, 0, Bm, ws + head.gw_off, head.in_p, head.out_p, head.in_p, B,
                                                      head.gw_slabs, head.w_size, s2);  // dL/dq fp32, hidden activations S8
     };
+    std::function<int()> deferred;  // side-stream launches of the layer above, held back until this layer's data gradient is enqueued
+#if defined(ISDQN_FORK_LATE)
+    const bool fork_late = ss != nullptr;
+#else
+    const bool fork_late = false;
+#endif
     for (int i = P.n_layers - 1; i >= 0; --i) {
         const Layer& l = P.L[i];
         const float* act_in = i > 0 ? ws + P.L[i - 1].act_off : nullptr;
@@ -2141,8 +2148,10 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
             rc = signal_priorities();
             if (rc) return rc;
             forked = true;
-            rc = run_head_deferred(lws);
-            if (rc) return rc;
+            if (!deferred) {  // (held-back side work of the layer above enqueues the two head kernels itself, behind this layer's data gradient)
+                rc = run_head_deferred(lws);
+                if (rc) return rc;
+            }
         }
         // data gradient for the layer below first: it reads this layer's weights, which the fused-Adam
         // weight-gradient epilogue below updates in place
@@ -2211,15 +2220,37 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
             }
             if (rc) return rc;
         }
+        if (deferred) {  // the side-stream work of the layer above, now that this layer's data gradient is enqueued
+            auto f = std::move(deferred);
+            deferred = nullptr;
+            rc = f();
+            if (rc) return rc;
+        }
         // weight gradient -> slabs (or straight into Adam when one workgroup holds the whole contraction)
+        bool defer_side = false;
+        hipEvent_t defer_event = nullptr;
         if (fork_after_dgrad) {  // dz is final AND the data gradient (which reads W) is enqueued: an in-place
-            rc = chain(ss, st, lws);  // fused-Adam update on the side stream cannot overtake it
-            if (rc) return rc;
-            rc = signal_priorities();
-            if (rc) return rc;
-            forked = true;
-            rc = run_head_deferred(lws);
-            if (rc) return rc;
+                                 // fused-Adam update on the side stream cannot overtake it
+            if (fork_late && i > 0) {
+                // Graph replay keeps the FIRST successor of a node on its queue and moves the others to another queue, where they
+                // start ~12 us late.  The successor that matters is the next data gradient: record the fork here,
+                // but create the side stream's kernels (loss_finalize, head weight gradient, this layer's weight gradient) only
+                // after that data gradient has been enqueued on the caller's stream.
+                defer_event = ss->ev[ss->next.fetch_add(1, std::memory_order_relaxed) % (unsigned)ss->n_ev];
+                ISDQN_HIP_CHECK(hipEventRecord(defer_event, st));
+                defer_side = true;
+                rc = signal_priorities();
+                if (rc) return rc;
+                forked = true;
+            } else {
+                rc = chain(ss, st, lws);
+                if (rc) return rc;
+                rc = signal_priorities();
+                if (rc) return rc;
+                forked = true;
+                rc = run_head_deferred(lws);
+                if (rc) return rc;
+            }
         }
         if (tail_swap && i == 1 && dz_fused) {  // layer 0's dz is final: its weight gradient may start beside this layer's
             rc = chain(ss, st, wst);
@@ -2228,63 +2259,88 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
             rc = run_head_deferred(wst);
             if (rc) return rc;
         }
-        int w_slabs;
-        bool fused_adam = false;
-        if (head_chained && ss) {  // enqueued by run_head_deferred()
-            add_entry_on(1, l.w_off, l.w_size, ws + l.gw_off, effective_splits(B, l.gw_slabs), l.w_size);
-            continue;
-        }
-        if (l.kind == 0) {
-            int img_slabs = 0;
-            rc = conv_wgrad_img(l, x3, in, act_in, dz_cur, ws + l.gw_off, B, lws, &img_slabs);
-            if (rc) return rc;
-            if (img_slabs) {
-                w_slabs = img_slabs;
-            } else {
-            if (l.is_u8) rc = x3 ? launch_conv_wgrad<2, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws)
-                                 : launch_conv_wgrad<1, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws);
-            else rc = x3 ? launch_conv_wgrad<3, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws)
-                         : launch_conv_wgrad<1, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws);
-            w_slabs = conv_wgrad_slabs(l, B);
+        // (the weight-gradient part of this layer as a closure: with ISDQN_FORK_LATE a layer that forks the side stream behind its
+        // own data gradient enqueues it only after the NEXT layer's data gradient is on the caller's stream -- see `deferred`)
+        const Layer* lp = &l;
+        auto wgrad_part = [&, lp, lws, head_chained, dz_cur, dz_ld, act_in]() -> int {
+            const Layer& l = *lp;
+            int rc = ISDQN_OK;
+            int w_slabs;
+            bool fused_adam = false;
+            if (head_chained && ss) {  // enqueued by run_head_deferred()
+                add_entry_on(1, l.w_off, l.w_size, ws + l.gw_off, effective_splits(B, l.gw_slabs), l.w_size);
+                return ISDQN_OK;
             }
-        } else {
-            // dW[out][in_p] = sum_b dz[b][out] * a[b][in_p] : both operands stored [K = b][rows]
-            MatSrc A{dz_cur, dz_ld, B, l.out_p, 1};
-            MatSrc Bm = l.in_unpadded_ld ? MatSrc{in.obs, l.in_unpadded_ld, B, l.in_f, 0}
-                                         : MatSrc{act_in, l.in_p, B, l.in_p, 1};
-            w_slabs = effective_splits(B, l.gw_slabs);
-            if (w_slabs == 1 && !l.in_unpadded_ld) {
-                fused_adam = true;  // (a gradient-only pass runs the same kernel with the stores of p / m / v switched off)
+            if (l.kind == 0) {
+                int img_slabs = 0;
+                rc = conv_wgrad_img(l, x3, in, act_in, dz_cur, ws + l.gw_off, B, lws, &img_slabs);
+                if (rc) return rc;
+                if (img_slabs) {
+                    w_slabs = img_slabs;
+                } else {
+                if (l.is_u8) rc = x3 ? launch_conv_wgrad<2, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws)
+                                     : launch_conv_wgrad<1, true>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws);
+                else rc = x3 ? launch_conv_wgrad<3, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws)
+                             : launch_conv_wgrad<1, false>(l, in, act_in, dz_cur, ws + l.gw_off, B, lws);
+                w_slabs = conv_wgrad_slabs(l, B);
+                }
+            } else {
+                // dW[out][in_p] = sum_b dz[b][out] * a[b][in_p] : both operands stored [K = b][rows]
+                MatSrc A{dz_cur, dz_ld, B, l.out_p, 1};
+                MatSrc Bm = l.in_unpadded_ld ? MatSrc{in.obs, l.in_unpadded_ld, B, l.in_f, 0}
+                                             : MatSrc{act_in, l.in_p, B, l.in_p, 1};
+                w_slabs = effective_splits(B, l.gw_slabs);
+                if (w_slabs == 1 && !l.in_unpadded_ld) {
+                    fused_adam = true;  // (a gradient-only pass runs the same kernel with the stores of p / m / v switched off)
 
-                AdamFuse af{params + l.w_off, adam_m + l.w_off, adam_v + l.w_off, ws + P.adam_tab_off,
-                            cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps,
-                            grad_out ? grad_out + l.w_off : nullptr, ws + P.wsplit_off + l.w_off, update ? 1 : 0};
-                // 64x64 tiles: the contraction is only B deep, the kernel lives off streaming p/m/v through the Adam
-                // epilogue, and 128x128 tiles would leave 100 workgroups for 256 CUs
-                // (operands: dz of a hidden layer -- or the fp32 dL/dq of the head -- and the S8 activations below it)
-                if (l.is_head)
-                    rc = x3 ? launch_plain<64, 64, 2, 2, true, true, 3, true, false, true, 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                             l.out_p, l.in_p, B, 1, 0, lws, &af)
-                            : launch_plain<64, 64, 2, 2, true, true, 1, true, false, true, 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                             l.out_p, l.in_p, B, 1, 0, lws, &af);
-                else
-                    rc = x3 ? launch_plain<64, 64, 2, 2, true, true, 3, true, false, true, DZ_S8 | 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                                     l.out_p, l.in_p, B, 1, 0, lws, &af)
-                            : launch_plain<64, 64, 2, 2, true, true, 1, true, false, true, DZ_S8 | 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
-                                                                                                     l.out_p, l.in_p, B, 1, 0, lws, &af);
-            } else if (l.in_unpadded_ld) {  // fc first layer: caller's fp32 observations
-                rc = plain_big<true, true, false, false, DZ_S8>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
-                                                                l.gw_slabs, l.w_size, lws);
-            } else if (l.is_head) {         // dL/dq is fp32, the hidden activations are S8
-                rc = plain_big<true, true, true, false, 2>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
-                                                           l.gw_slabs, l.w_size, lws);
-            } else {
-                rc = plain_big<true, true, true, false, DZ_S8 | 2>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
-                                                                   l.gw_slabs, l.w_size, lws);
+                    AdamFuse af{params + l.w_off, adam_m + l.w_off, adam_v + l.w_off, ws + P.adam_tab_off,
+                                cfg->learning_rate, cfg->adam_b1, cfg->adam_b2, cfg->adam_eps,
+                                grad_out ? grad_out + l.w_off : nullptr, ws + P.wsplit_off + l.w_off, update ? 1 : 0};
+                    // 64x64 tiles: the contraction is only B deep, the kernel lives off streaming p/m/v through the Adam
+                    // epilogue, and 128x128 tiles would leave 100 workgroups for 256 CUs
+                    // (operands: dz of a hidden layer -- or the fp32 dL/dq of the head -- and the S8 activations below it)
+                    if (l.is_head)
+                        rc = x3 ? launch_plain<64, 64, 2, 2, true, true, 3, true, false, true, 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                                 l.out_p, l.in_p, B, 1, 0, lws, &af)
+                                : launch_plain<64, 64, 2, 2, true, true, 1, true, false, true, 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                                 l.out_p, l.in_p, B, 1, 0, lws, &af);
+                    else
+                        rc = x3 ? launch_plain<64, 64, 2, 2, true, true, 3, true, false, true, DZ_S8 | 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                                         l.out_p, l.in_p, B, 1, 0, lws, &af)
+                                : launch_plain<64, 64, 2, 2, true, true, 1, true, false, true, DZ_S8 | 2>(A, nullptr, 0, Bm, nullptr, l.in_p,
+                                                                                                         l.out_p, l.in_p, B, 1, 0, lws, &af);
+                } else if (l.in_unpadded_ld) {  // fc first layer: caller's fp32 observations
+                    rc = plain_big<true, true, false, false, DZ_S8>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
+                                                                    l.gw_slabs, l.w_size, lws);
+                } else if (l.is_head) {         // dL/dq is fp32, the hidden activations are S8
+                    rc = plain_big<true, true, true, false, 2>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
+                                                               l.gw_slabs, l.w_size, lws);
+                } else {
+                    rc = plain_big<true, true, true, false, DZ_S8 | 2>(x3, A, nullptr, 0, Bm, ws + l.gw_off, l.in_p, l.out_p, l.in_p, B,
+                                                                       l.gw_slabs, l.w_size, lws);
+                }
             }
+            if (rc) return rc;
+            if (!fused_adam) add_entry_on(lws == wst && ss ? 1 : 0, l.w_off, l.w_size, ws + l.gw_off, w_slabs, l.w_size);
+            return ISDQN_OK;
+        };
+        if (defer_side) {
+            hipEvent_t e = defer_event;
+            deferred = [&, e, lws, wgrad_part]() -> int {
+                ISDQN_HIP_CHECK(hipStreamWaitEvent(lws, e, 0));
+                if (int r = run_head_deferred(lws)) return r;
+                return wgrad_part();
+            };
+        } else {
+            rc = wgrad_part();
+            if (rc) return rc;
         }
+    }
+    if (deferred) {
+        auto f = std::move(deferred);
+        deferred = nullptr;
+        rc = f();
         if (rc) return rc;
-        if (!fused_adam) add_entry_on(lws == wst && ss ? 1 : 0, l.w_off, l.w_size, ws + l.gw_off, w_slabs, l.w_size);
     }
     if (head_deferred) {  // no layer forked: keep the two kernels in line
         rc = run_head_deferred(st);
