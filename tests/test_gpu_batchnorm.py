@@ -278,3 +278,32 @@ def test_tfdqn_with_batchnorm_matches_the_oracle():
     for m in exp:
         for n in exp[m]:
             assert np.abs(after["params"][m][n] - exp[m][n]).max() < 2.001e-3, (m, n)  # one Adam step of lr = 1e-3
+
+
+@pytest.mark.parametrize("algo, arch", [("isdqn", "cnn"), ("tfdqn", "cnn"), ("isdqn", "impala")])
+def test_entry_points_with_the_batch_norm_flag(tmp_path, algo, arch):
+    """`-bn` through the reference's entry points (experiments/atari/isdqn.py, tfdqn.py; launch_job/atari/launch.sh BATCH_NORM=1):
+    training runs, the vectorised acting path reads the running averages, and the saved model carries both Flax collections."""
+    import json
+    import pickle
+
+    from experiments.atari import isdqn as e_isdqn, tfdqn as e_tfdqn
+
+    run = {"isdqn": e_isdqn.run, "tfdqn": e_tfdqn.run}[algo]
+    name = f"bn{algo}{arch}_Synthetic"
+    argv = ["-en", name, "-s", "1", "-dw", "-f", "8", "8", "8", "16", "-rbc", "200", "-bs", "8", "-n", "1", "-horizon", "40", "-at", arch,
+            "-ne", "2", "-ntspe", "48", "-utd", "4", "-nis", "16", "-ed", "100", "-ln", "-bn", "-tuf", "16", "-env", "synthetic", "-nenvs", "2"]
+    if algo == "isdqn":
+        argv += ["-nbi", "2"]
+    run(argv, root=str(tmp_path))
+    out = tmp_path / "atari" / "exp_output" / name
+    assert json.load(open(out / "parameters.json"))[algo]["batch_norm"] is True  # (an agent parameter: parser_argument.py:27-36)
+    model = pickle.load(open(out / algo / "models" / "1", "rb"))
+    assert set(model) == {"params", "batch_stats"}
+    stats = model["batch_stats"]
+    top = stats["BatchNorm_0"]
+    assert top["mean"].shape == (84, 84) and float(np.abs(top["mean"]).max()) > 0.0  # moved off Flax's initial (0, 1) by the learn steps
+    if arch == "impala":
+        assert stats["Stack_2"]["BatchNorm_1"]["var"].shape == (11, 11) and model["params"]["Stack_0"]["BatchNorm_0"]["scale"].shape == (42, 42)
+    else:
+        assert model["params"]["BatchNorm_3"]["scale"].shape == (11 * 11 * 8,) and stats["BatchNorm_4"]["var"].shape == (16,)
