@@ -267,6 +267,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ?
         const int which = tid >> 6, ch = tid & 63;
         const float* src = which == 0 ? p.bias : which == 1 ? p.gamma : p.beta;
         const bool ok = kg == 0 && tid < 192 && ch < g.cout_p && src != nullptr;
+        ISDQN_BOUNDS_CHECK(ok ? src + ch : zero_chunk(), 4, 13);
         par_v = *(const ISDQN_GLOBAL float*)(ok ? src + ch : zero_chunk());
     }
 
@@ -902,6 +903,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
         const int which = tid >> 6, ch = tid & 63;
         const float* src = which == 0 ? p.gamma : p.beta;
         const bool ok = tid < 128 && ch < g.cin_p && p.gamma != nullptr;
+        ISDQN_BOUNDS_CHECK(ok ? src + ch : zero_chunk(), 4, 13);
         par_v = *(const ISDQN_GLOBAL float*)(ok ? src + ch : zero_chunk());
     }
 
@@ -1038,6 +1040,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int ch0 = mt * 16 + grp * 4;
+            ISDQN_BOUNDS_CHECK(ch0 < g.cin_p ? p.z_in + pixel * g.cin_p + ch0 : zero_chunk(), 16, 12);
             const ISDQN_GLOBAL f32x4* zp = (const ISDQN_GLOBAL f32x4*)(ch0 < g.cin_p ? p.z_in + pixel * g.cin_p + ch0 : zero_chunk());
             const f32x4 zq = *zp;
             zpre[nt][mt][0] = zq[0]; zpre[nt][mt][1] = zq[1]; zpre[nt][mt][2] = zq[2]; zpre[nt][mt][3] = zq[3];

@@ -480,6 +480,36 @@ __device__ __forceinline__ float row16_sum(float x) {
 static __device__ const float isdqn_zero_block[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                                                       0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 __device__ __forceinline__ const float* zero_chunk() { return isdqn_zero_block; }
+
+// Bounds-checked development build (-DISDQN_BOUNDS, tests/test_gpu_bounds.py): every global LOAD of the operand loaders, the image
+// fills, the frame-id table and the prefetching epilogues is checked against the byte extents the caller registered
+// (isdqn_debug_bounds_set: the exact extents of every tensor it hands to the library) plus the zero block.  The first load
+// outside all of them is recorded (address + site number) instead of going unnoticed: an out-of-range read whose value is never
+// used computes right results and only faults when the tensor happens to end a mapped segment (round 2's fc abort).
+#if defined(ISDQN_BOUNDS)
+struct BoundsTable {
+    int n, bad, bad_site, pad;
+    unsigned long long bad_addr;
+    unsigned long long lo[64], hi[64];
+};
+static __device__ BoundsTable isdqn_bounds;
+__device__ __forceinline__ void bounds_check(const void* p, int bytes, int site) {
+    const unsigned long long a = (unsigned long long)p, b = a + (unsigned)bytes;
+    const unsigned long long z = (unsigned long long)isdqn_zero_block;
+    if (a >= z && b <= z + sizeof(isdqn_zero_block)) return;
+    const int n = isdqn_bounds.n;
+    if (n <= 0) return;
+    bool ok = false;
+    for (int i = 0; i < n; ++i) ok |= (a >= isdqn_bounds.lo[i] && b <= isdqn_bounds.hi[i]);
+    if (!ok && atomicCAS(&isdqn_bounds.bad, 0, 1) == 0) {
+        isdqn_bounds.bad_addr = a;
+        isdqn_bounds.bad_site = site;
+    }
+}
+#define ISDQN_BOUNDS_CHECK(p, bytes, site) bounds_check((const void*)(p), (int)(bytes), (site))
+#else
+#define ISDQN_BOUNDS_CHECK(p, bytes, site) ((void)0)
+#endif
 __device__ __forceinline__ void mask8(bool ok, float (&v)[8]) {  // for data that is already being consumed
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = ok ? v[i] : 0.f;
@@ -489,6 +519,7 @@ __device__ __forceinline__ void mask8(bool ok, float (&v)[8]) {  // for data tha
 // which counts on both wait counters and completes out of order, so every wait turns into vmcnt(0) lgkmcnt(0)).
 #define ISDQN_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ void load8_aligned(const float* p, float (&v)[8]) {
+    ISDQN_BOUNDS_CHECK(p, 32, 1);
     const ISDQN_GLOBAL f32x4* gp = (const ISDQN_GLOBAL f32x4*)p;
     const f32x4 a = gp[0];
     const f32x4 b = gp[1];
@@ -497,6 +528,7 @@ __device__ __forceinline__ void load8_aligned(const float* p, float (&v)[8]) {
 }
 __device__ __forceinline__ unsigned long long load_u64_unaligned(const uint8_t* p) {
     typedef unsigned long long __attribute__((aligned(1))) u64_u;
+    ISDQN_BOUNDS_CHECK(p, 8, 2);
     return *(const ISDQN_GLOBAL u64_u*)p;
 }
 
@@ -517,6 +549,7 @@ struct MatSrc {
         } else {
             const float* p = base + (ok ? (int64_t)o * ld + i0 : (int64_t)0);
             const int last = ok ? inner - 1 - i0 : 0;  // last valid element offset in this chunk
+            ISDQN_BOUNDS_CHECK(p, 4 * ((last < 7 ? last : 7) + 1), 3);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float x = p[j <= last ? j : last];

@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void dense_post_kernel(const float* __restrict
             const float* src = w == 0 ? bias : w == 1 ? gamma : beta;
 #pragma unroll
             for (int e = 0; e < 2; ++e)
+            {
+                ISDQN_BOUNDS_CHECK((src != nullptr && c + e < F) ? src + c + e : zero_chunk(), 4, 28);
                 par[w][e] = *(const ISDQN_GLOBAL float*)((src != nullptr && c + e < F) ? src + c + e : zero_chunk());
+            }
         }
         float v0 = 0.f, v1 = 0.f;
         const float* p = slabs + (int64_t)row * row_pitch + c;
@@ -511,21 +514,29 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
     // ---- operands of the later phases (raw: converted where they are used) ----
     int act[SMAX];  // action of the S transitions (selects the head rows the data gradient reads)
 #pragma unroll
-    for (int s = 0; s < SMAX; ++s) act[s] = *(const ISDQN_GLOBAL int*)((s < S && b0 + s < p.B) ? (const void*)(p.action + b0 + s) : zero_chunk());
+    for (int s = 0; s < SMAX; ++s) {
+        ISDQN_BOUNDS_CHECK((s < S && b0 + s < p.B) ? (const void*)(p.action + b0 + s) : zero_chunk(), 4, 20);
+        act[s] = *(const ISDQN_GLOBAL int*)((s < S && b0 + s < p.B) ? (const void*)(p.action + b0 + s) : zero_chunk());
+    }
     float td_r;          // reward, terminal flag of this thread's (transition, head) pair
     uint8_t td_term;
     {
         const int s = tid / K;
         const bool ok = tid < S * K && b0 + s < p.B;
+        ISDQN_BOUNDS_CHECK(ok ? (const void*)(p.reward + b0 + s) : zero_chunk(), 4, 21);
+        ISDQN_BOUNDS_CHECK(ok ? (const void*)(p.terminal + b0 + s) : zero_chunk(), 1, 22);
         td_r = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.reward + b0 + s) : zero_chunk());
         td_term = *(const ISDQN_GLOBAL uint8_t*)(ok ? (const void*)(p.terminal + b0 + s) : zero_chunk());
     }
+    ISDQN_BOUNDS_CHECK(tid < p.O ? (const void*)(p.bias + tid) : zero_chunk(), 4, 23);
     const float bias_v = *(const ISDQN_GLOBAL float*)(tid < p.O ? (const void*)(p.bias + tid) : zero_chunk());
     float ga[COLS], be[COLS];
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
         const int c = tid + j * HC_THREADS;
         const bool ok = p.gamma != nullptr && c < p.F;
+        ISDQN_BOUNDS_CHECK(ok ? (const void*)(p.gamma + c) : zero_chunk(), 4, 24);
+        ISDQN_BOUNDS_CHECK(ok ? (const void*)(p.beta + c) : zero_chunk(), 4, 24);
         ga[j] = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.gamma + c) : zero_chunk());
         be[j] = *(const ISDQN_GLOBAL float*)(ok ? (const void*)(p.beta + c) : zero_chunk());
     }
@@ -549,14 +560,20 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
         for (int c0 = q * 4; c0 < Fp; c0 += TPR * 4) {  // (one pass up to 512 columns)
             float hb4[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hb4[e] = *(const ISDQN_GLOBAL float*)(c0 + e < p.F ? (const void*)(p.hbias + c0 + e) : zero_chunk());
+            for (int e = 0; e < 4; ++e) {
+                ISDQN_BOUNDS_CHECK(c0 + e < p.F ? (const void*)(p.hbias + c0 + e) : zero_chunk(), 4, 25);
+                hb4[e] = *(const ISDQN_GLOBAL float*)(c0 + e < p.F ? (const void*)(p.hbias + c0 + e) : zero_chunk());
+            }
             const ISDQN_GLOBAL f32x4* base = (const ISDQN_GLOBAL f32x4*)(row_ok ? (const void*)(p.slabs + grow * p.row_pitch + c0) : zero_chunk());
             const int64_t strd = row_ok ? p.slab_stride / 4 : 0;  // (Fp is a multiple of 8)
             f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int s0 = 0; s0 < p.n_slabs; s0 += SB) {
                 f32x4 t[SB];
 #pragma unroll
-                for (int u = 0; u < SB; ++u) t[u] = base[min(s0 + u, p.n_slabs - 1) * strd];  // tail: clamped, masked in the sum
+                for (int u = 0; u < SB; ++u) {
+                    ISDQN_BOUNDS_CHECK((const void*)(base + min(s0 + u, p.n_slabs - 1) * strd), 16, 26);
+                    t[u] = base[min(s0 + u, p.n_slabs - 1) * strd];  // tail: clamped, masked in the sum
+                }
 #pragma unroll
                 for (int u = 0; u < SB; ++u)
                     if (s0 + u < p.n_slabs) sum += t[u];  // (uniform condition; slab order)
@@ -707,6 +724,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainP
 #pragma unroll
                 for (int j = 0; j < COLS; ++j) {
                     const int c = tid + j * HC_THREADS;
+                    ISDQN_BOUNDS_CHECK(wr + (c < p.F ? c : 0), 4, 27);
                     w[s][u][j] = *(const ISDQN_GLOBAL float*)(wr + (c < p.F ? c : 0));
                 }
             }
@@ -1704,6 +1722,28 @@ static int bn_site_backward(const BnSite& b, const float* params, float* ws, flo
 }  // namespace isdqn
 
 using namespace isdqn;
+
+#if defined(ISDQN_BOUNDS)
+// Bounds-checked development build (gemm_core.h: ISDQN_BOUNDS_CHECK): register the byte extents of every tensor the caller hands to
+// the library -- [lo[i], hi[i]) -- and clear the record; read back the first load that fell outside all of them (synchronises).
+extern "C" int isdqn_debug_bounds_set(const uint64_t* lo, const uint64_t* hi, int32_t n) {
+    ISDQN_REQUIRE(n >= 0 && n <= 64, ISDQN_ERR_ARG, "at most 64 regions");
+    isdqn::BoundsTable t;
+    memset(&t, 0, sizeof(t));
+    t.n = n;
+    for (int i = 0; i < n; ++i) { t.lo[i] = lo[i]; t.hi[i] = hi[i]; }
+    ISDQN_HIP_CHECK(hipDeviceSynchronize());
+    ISDQN_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(isdqn::isdqn_bounds), &t, sizeof(t)));
+    return ISDQN_OK;
+}
+extern "C" int isdqn_debug_bounds_get(int32_t* bad, int32_t* site, uint64_t* addr) {
+    isdqn::BoundsTable t;
+    ISDQN_HIP_CHECK(hipDeviceSynchronize());
+    ISDQN_HIP_CHECK(hipMemcpyFromSymbol(&t, HIP_SYMBOL(isdqn::isdqn_bounds), sizeof(t)));
+    *bad = t.bad; *site = t.bad_site; *addr = t.bad_addr;
+    return ISDQN_OK;
+}
+#endif
 
 // =============================================================================================
 // C ABI

@@ -30,8 +30,11 @@ struct FrameSrc {
         if (ids == nullptr) return j * stack + c;  // (development experiment, conv_img.h)
 #endif
         if (paired_B > 0) {
-            return j < paired_B ? ids[(int64_t)j * 2 * stack + c] : ids[(int64_t)(j - paired_B) * 2 * stack + stack + c];
+            const int* q = j < paired_B ? ids + (int64_t)j * 2 * stack + c : ids + (int64_t)(j - paired_B) * 2 * stack + stack + c;
+            ISDQN_BOUNDS_CHECK(q, 4, 4);
+            return *q;
         }
+        ISDQN_BOUNDS_CHECK(ids + (int64_t)j * (id_pitch ? id_pitch : stack) + id_off + c, 4, 4);
         return ids[(int64_t)j * (id_pitch ? id_pitch : stack) + id_off + c];
     }
     // 8 horizontally adjacent pixels (ix0 .. ix0+7) of row iy of frame `id`, zero outside the frame; exact in
@@ -173,6 +176,9 @@ struct PlainGemm {
                 const int row = t.m0 + rl, col = t.n0 + c4;
                 on[it] = row < M && col < N;  // N and ldc are multiples of 4: a float4 never straddles the edge
                 off[it] = on[it] ? (int64_t)row * ldc + col : 0;
+                ISDQN_BOUNDS_CHECK(adam.m + off[it], 16, 10);
+                ISDQN_BOUNDS_CHECK(adam.v + off[it], 16, 10);
+                ISDQN_BOUNDS_CHECK(adam.p + off[it], 16, 10);
                 pm[it] = *(const ISDQN_GLOBAL f32x4*)(adam.m + off[it]);
                 pv[it] = *(const ISDQN_GLOBAL f32x4*)(adam.v + off[it]);
                 pp[it] = *(const ISDQN_GLOBAL f32x4*)(adam.p + off[it]);
@@ -294,7 +300,10 @@ struct DenseDgradLN {
                 const int row = m_wave + mt * 16 + grp * 4 + r;
                 const int64_t base = (int64_t)(row < M ? row : 0) * ldc + t.n0;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) zall[mt][r][nt] = *(const ISDQN_GLOBAL float*)(z + base + nt * 16 + li);
+                for (int nt = 0; nt < NT; ++nt) {
+                    ISDQN_BOUNDS_CHECK(z + base + nt * 16 + li, 4, 11);
+                    zall[mt][r][nt] = *(const ISDQN_GLOBAL float*)(z + base + nt * 16 + li);
+                }
             }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)

@@ -18,7 +18,7 @@ def pytest_configure(config):
 # replay buffer known answers), then the GEMM engine, the network against the oracle, and the composite agent / graph /
 # baseline tests last -- a fault late in the suite cannot hide the cheap bit-exact rows under `-x`.
 _GPU_ORDER = ["test_gpu_sum_tree", "test_gpu_replay_kernels", "test_gpu_replay_buffer", "test_gpu_gemm", "test_gpu_network",
-              "test_gpu_fullsize_properties", "test_gpu_dqn_baselines", "test_gpu_impala", "test_gpu_batchnorm", "test_gpu_analysis", "test_gpu_analysis_agents", "test_gpu_graphed_update",
+              "test_gpu_fullsize_properties", "test_gpu_bounds", "test_gpu_dqn_baselines", "test_gpu_impala", "test_gpu_batchnorm", "test_gpu_analysis", "test_gpu_analysis_agents", "test_gpu_graphed_update",
               "test_gpu_agent", "test_gpu_rccl_world1"]
 
 
