@@ -12,6 +12,7 @@
 #include <functional>
 
 #include "conv_img.h"
+#include "conv_u8_pair.h"
 #include "conv_ws.h"
 #include "net_plan.h"
 #include "net_problems.h"
@@ -1255,6 +1256,13 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const floa
 #endif
     *done = true;
     if (l.is_u8) {
+#if !defined(ISDQN_NO_U8_PAIR)
+        // two pixel tiles per workgroup, the second one's frame rows prefetched into registers (conv_u8_pair.h): the tile image
+        // must be one batch of 2 x 256 positions, the frame ids four at most
+        // (four stacked frames: K = 256, eight K steps as straight-line code)
+        if (mt == 2 && ip.tiles_per_img % 2 == 0 && ip.R * (ip.Wp / 8) <= U8P_PB * GEMM_THREADS && l.cin == 4 && l.K == 256 && ip.ablate == 0)
+            return passes == 2 ? launch_conv_fwd_u8_pair<2, 8>(ip, st) : launch_conv_fwd_u8_pair<1, 8>(ip, st);
+#endif
         if (passes == 2) return mt == 2 ? launch_conv_fwd_img<2, 2, true>(ip, st) : launch_conv_fwd_img<4, 2, true>(ip, st);
         return mt == 2 ? launch_conv_fwd_img<2, 1, true>(ip, st) : launch_conv_fwd_img<4, 1, true>(ip, st);
     }

@@ -338,3 +338,26 @@ def test_fc_architecture_lunar_lander_shape(shape, precision):
     for mod in p:
         for leaf in p[mod]:
             assert np.abs(got[mod][leaf] - p[mod][leaf].numpy()).max() < 3e-4, (mod, leaf)
+
+
+def test_first_layer_pair_kernel_is_bit_identical_to_the_one_tile_kernel():
+    """csrc/conv_u8_pair.h (two pixel tiles per workgroup, the second one's frame rows prefetched into registers) against the
+    one-tile kernel it replaces for 84x84x4 stacks (-DISDQN_NO_U8_PAIR build of the same sources): parameters, Adam moments, losses,
+    q-values, targets and priorities after three learn steps, the loss-only pass and a one-row forward of eight cnn shapes (c2 and c5
+    at full size among them) hash to the same bits (scripts/r2/bits.py)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "is-dqn_amd"))
+    import build
+
+    old = build.build(verbose=False, variant="nopair", defines=("ISDQN_NO_U8_PAIR",))
+    outs = []
+    for lib in (old, build.LIB):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "r2", "bits.py")], env=dict(os.environ, ISDQN_HIP_LIB=lib),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if "params" in l])
+    assert len(outs[0]) >= 8 and outs[0] == outs[1]
