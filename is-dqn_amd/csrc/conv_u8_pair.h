@@ -311,6 +311,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void conv_fwd_u8_pair_kernel(const
                         zp[r] = zv[nt][mt][r];
                     }
                     s8_store_quad_paired(p.act + pix * g.cout_p, ch0, a.x, a.y, a.z, a.w);
+                    // (a nontemporal store of z -- not read before the backward -- was measured: 26.5 -> 28.0 us)
                     if (j < p.z_img) *reinterpret_cast<float4*>(p.z + pix * g.cout_p + ch0) = zq;
                 }
             }
