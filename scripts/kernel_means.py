@@ -8,7 +8,7 @@ def load(d):
     df = pd.read_csv(f).sort_values("Start_Timestamp").reset_index(drop=True)
     df["k"] = df.Kernel_Name.map(lambda n: re.sub(r"\(.*", "", n).replace("isdqn::", "").replace("void ", "")[:62])
     df["dur"] = (df.End_Timestamp - df.Start_Timestamp) / 1e3
-    starts = df[df.k.str.contains("conv_fwd_img_kernel<2, 2, true")].Start_Timestamp.values
+    starts = df[df.k.str.contains("conv_fwd_img_kernel<2, 2, true|conv_fwd_u8_pair_kernel<2")].Start_Timestamp.values
     per = (starts[1:] - starts[:-1]) / 1e3
     per = per[per < 2 * pd.Series(per).median()]
     # steady state only: drop the first third

@@ -10,7 +10,7 @@ import pandas as pd
 df = pd.read_csv(sys.argv[1]).sort_values("Start_Timestamp").reset_index(drop=True)
 df["k"] = df.Kernel_Name.map(lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n).replace("isdqn::", ""))[:90])
 df = df.iloc[len(df) // 3:].reset_index(drop=True)
-is_anchor = df.k.str.contains("conv_fwd_img_kernel<2, 2, true") | df.k.str.contains("conv_fwd_img_kernel<2, 1, true")
+is_anchor = df.k.str.contains("conv_fwd_img_kernel<2, 2, true|conv_fwd_u8_pair_kernel<2") | df.k.str.contains("conv_fwd_img_kernel<2, 1, true|conv_fwd_u8_pair_kernel<1")
 starts = np.flatnonzero(is_anchor.values)
 rows = {}
 periods = []
