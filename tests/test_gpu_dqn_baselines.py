@@ -193,3 +193,80 @@ def test_every_leaf_gradient_of_the_single_head_losses_matches_the_oracle(kind):
         after = eng.export_flax()["Dense_1"]["bias"]
         big = np.abs(o_grads["Dense_1"]["bias"].numpy()) > 1e-3
         assert big.any() and (np.abs(after - before)[big] > 0.5e-3).all()
+
+
+FC_PLANS = [
+    # (features, obs dim, A, B): a 2-layer all-dense plan (one hidden layer + head) and the 3-layer LunarLander plan -- the branch
+    # combinations of the backward's tail that no cnn network takes (round 2's abort sat in the 3-layer one)
+    pytest.param(((64,), 8, 4, 32), id="fc-2-layer-plan-64"),
+    pytest.param(((100, 100), 8, 4, 32), id="fc-3-layer-plan-100x100"),
+    pytest.param(((24, 40, 16), 6, 3, 10), id="fc-4-layer-plan-B10"),
+]
+
+
+@pytest.mark.parametrize("plan", FC_PLANS)
+@pytest.mark.parametrize("kind", ["tfdqn", "dqn"])
+def test_fc_plans_of_the_baselines_match_the_oracle(kind, plan):
+    """DQN / TF-DQN on all-dense plans (dqn.py:59-93, tfdqn.py:56-93 with architecture_type="fc"): loss, targets, every leaf's gradient
+    of the first step through Adam's first update (p -= lr g / (|g| + eps) element by element), three chained steps."""
+    from oracle import network as onet
+    from oracle.dqn import DQN as ODQN, TFDQN as OTF
+    from oracle.replay_buffer import ReplayElement
+    from slimdqn.networks.dqn import DQN
+    from slimdqn.networks.tfdqn import TFDQN
+
+    feats, d, A, B = plan
+    lr, eps = 1e-3, 1e-8
+    params = perturbed_params(4, (d,), feats, "fc", A, True)
+    if kind == "dqn":
+        hip = DQN(0, (d,), A, list(feats), True, "fc", lr, 0.99, 1, 1, 4, adam_eps=eps, batch_size=B)
+        ora = ODQN(0, (d,), A, list(feats), True, "fc", lr, 0.99, 1, 1, 4, adam_eps=eps, params=params, dtype=torch.float64)
+    else:
+        hip = TFDQN(0, (d,), A, list(feats), True, False, "fc", lr, 0.99, 1, 1, 4, adam_eps=eps, batch_size=B)
+        ora = OTF(0, (d,), A, list(feats), True, False, "fc", lr, 0.99, 1, 1, 4, adam_eps=eps, params=params, dtype=torch.float64)
+    eng = hip._engine
+    eng.import_flax(params)
+    if kind == "dqn":
+        hip.target_params = hip.params.copy()
+    rng = np.random.default_rng(9)
+    st, nx = rng.normal(size=(B, d)).astype(np.float32), rng.normal(size=(B, d)).astype(np.float32)
+    action = rng.integers(0, A, B).astype(np.int32)
+    reward = rng.normal(size=B).astype(np.float32)
+    terminal = (rng.random(B) < 0.3).astype(np.uint8)
+    ref = ReplayElement(state=st, action=action.astype(np.int64), reward=reward.astype(np.float64), next_state=nx, is_terminal=terminal.astype(np.int64))
+    dev = lambda a: torch.from_numpy(a).cuda()
+    batch = eng.make_batch(state=dev(st), next_state=dev(nx), action=dev(action), reward=dev(reward), terminal=dev(terminal))
+    if kind == "dqn":
+        o_q, o_t, o_td = ora.loss_terms(ora.params, ora.target_params, ref)
+        loss = eng.loss_on_batch_target(batch, hip.target_params.tensor).cpu().numpy()
+        o_grads, _ = ora.grads(ora.params, ora.target_params, ref)
+    else:
+        o_q, o_t, o_td = ora.loss_terms(ora.params, ref)
+        loss = eng.loss_on_batch(batch).cpu().numpy()
+        o_grads, _ = ora.grads(ora.params, ref)
+    assert np.abs(eng.q_values.cpu().numpy()[:, 0] - o_q.detach().numpy()).max() < 1e-3
+    assert np.abs(eng.targets.cpu().numpy()[:, 0] - o_t.detach().numpy()).max() < 1e-3
+    assert abs(loss[0] - float(o_td.mean())) < 1e-3 * max(1.0, float(o_td.mean()))
+    # first step: the update IS the gradient (Adam's first step, eps = 1e-8: p -= lr * sign(g) wherever |g| >> eps), so the gradient
+    # of every leaf is read off a gradient-only pass and held to the oracle's
+    g = torch.zeros_like(eng.params)
+    eng.grad_on_batch(batch, g, target_params=hip.target_params.tensor if kind == "dqn" else None)
+    hg = eng.internal_to_flax_grads(g)
+    for mod in o_grads:
+        for leaf in o_grads[mod]:
+            a, b = np.asarray(hg[mod][leaf], np.float64), o_grads[mod][leaf].numpy()
+            assert np.abs(a - b).max() < 3e-3 * max(np.abs(b).max(), 1e-12), (mod, leaf)
+    p, s_opt = ora.params, ora.optimizer_state
+    for step in range(3):
+        if kind == "dqn":
+            p, s_opt, o_loss = ora.learn_on_batch(p, ora.target_params, s_opt, ref)
+            h_loss = eng.learn_on_batch_target(batch, hip.target_params.tensor).cpu().numpy()[0]
+        else:
+            p, s_opt, o_loss = ora.learn_on_batch(p, s_opt, ref)
+            h_loss = eng.learn_on_batch(batch).cpu().numpy()[0]
+        assert abs(float(h_loss) - o_loss) < (1e-3 if step == 0 else 5e-3) * max(1.0, abs(o_loss)), f"step {step}"
+    got = hip.get_model()["params"]
+    for mod in p:
+        for leaf in p[mod]:
+            assert np.abs(got[mod][leaf] - p[mod][leaf].numpy()).max() < 3 * 2.001e-3, (mod, leaf)
+    assert int(eng.adam_count.item()) == 3

@@ -118,3 +118,44 @@ def test_batch_permutation_permutes_rows_and_keeps_losses(shape):
     np.testing.assert_allclose(p0[perm], p1, rtol=1e-4, atol=1e-6)
     # the loss is a mean over the batch: same up to the summation order
     np.testing.assert_allclose(l0, l1, rtol=1e-5)
+
+
+FC_PLANS = [pytest.param(((64,), 8, 1, 4, 32), id="fc-2-layer-plan"), pytest.param(((100, 100), 8, 1, 4, 32), id="fc-3-layer-lunar-lander"),
+            pytest.param(((300, 600), 8, 3, 5, 1000), id="fc-wide-B1000")]
+
+
+@pytest.mark.parametrize("plan", FC_PLANS)
+def test_all_dense_plans_are_run_to_run_identical_and_consistent_with_the_forward_path(plan):
+    """The same properties for all-dense networks (BASELINE configs[0] and the plans around it): the backward's tail takes other
+    branches there than in any cnn network (net_kernels.hip: `tail_swap` without a fused data gradient, the unaligned first-layer
+    operand on the side stream), so determinism and the learn path against the forward-only path are held on them too."""
+    from slimdqn._engine import QNetEngine
+
+    feats, d, K, A, B = plan
+    rng = np.random.default_rng(3)
+    st, nx = rng.normal(size=(B, d)).astype(np.float32), rng.normal(size=(B, d)).astype(np.float32)
+    action = rng.integers(0, A, B).astype(np.int32)
+    reward = rng.normal(size=B).astype(np.float32)
+    terminal = (rng.random(B) < 0.2).astype(np.uint8)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    outs = []
+    for rep in range(3):
+        eng = QNetEngine((d,), A, 1 + K, feats, "fc", True, B, gamma_n=GAMMA_N, learning_rate=1e-3, adam_eps=1e-8)
+        eng.init_params(7)
+        batch = eng.make_batch(state=dev(st), next_state=dev(nx), action=dev(action), reward=dev(reward), terminal=dev(terminal))
+        if rep == 0:  # q / targets / losses of the learn path against a host evaluation of forward() on the same parameters
+            q = eng.forward(obs=dev(np.concatenate([st, nx])), n_rows=2 * B).cpu().numpy().astype(np.float64).reshape(2 * B, 1 + K, A)
+            qv = q[np.arange(B), 1:, :][np.arange(B), :, action]
+            tg = reward[:, None] + (1.0 - terminal[:, None]) * GAMMA_N * q[B:, :K].max(-1)
+            pre = eng.loss_on_batch(batch).cpu().numpy()
+            np.testing.assert_allclose(eng.q_values.cpu().numpy(), qv, atol=1e-3)
+            np.testing.assert_allclose(eng.targets.cpu().numpy(), tg, atol=1e-3)
+            np.testing.assert_allclose(pre, ((qv - tg) ** 2).mean(0), rtol=1e-3, atol=1e-3)
+        losses = [eng.learn_on_batch(batch).cpu().numpy().copy() for _ in range(4)]
+        if rep == 0:
+            np.testing.assert_allclose(losses[0], pre, rtol=1e-5, atol=1e-6)  # loss_on_batch == the step that follows it
+        outs.append((eng.params.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy(), np.stack(losses),
+                     eng.priorities.cpu().numpy().copy()))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
