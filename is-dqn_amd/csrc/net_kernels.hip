@@ -13,6 +13,7 @@
 
 #include "conv_img.h"
 #include "conv_u8_pair.h"
+#include "conv_s8_pair.h"
 #include "conv_ws.h"
 #include "net_plan.h"
 #include "net_problems.h"
@@ -1272,6 +1273,12 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const floa
     static const bool no_kg = ISDQN_DEV_ENV("ISDQN_NO_KGROUPS");
     const bool kg2 = !no_kg && mt == 4 && lds > 80 * 1024 && lds + stage_bytes <= LDS_LIMIT &&
                      mt * 16 * 128 * 4 <= lds - stage_bytes && l.K >= 8 * GEMM_BK;
+#if !defined(ISDQN_NO_U8_PAIR)
+    // two images per workgroup, the second one prefetched into registers (conv_s8_pair.h): the one-workgroup-per-CU layer with 16 K steps
+    if (passes == 3 && mt == 4 && kg2 && ip.tiles_per_img == 1 && l.K == 512 && n_img % 2 == 0 && ip.ablate == 0 && ip.stamps == nullptr &&
+        ip.R * ip.Wp * (l.cin_p / 8) <= S8P_BATCH * GEMM_THREADS * 2)
+        return launch_conv_fwd_s8_pair<8>(ip, st);
+#endif
     if (passes == 3) return mt == 2 ? launch_conv_fwd_img<2, 3, false>(ip, st)
                           : kg2 ? launch_conv_fwd_img<4, 3, false, 2>(ip, st) : launch_conv_fwd_img<4, 3, false>(ip, st);
     return mt == 2 ? launch_conv_fwd_img<2, 1, false>(ip, st)

@@ -341,8 +341,9 @@ def test_fc_architecture_lunar_lander_shape(shape, precision):
 
 
 def test_first_layer_pair_kernel_is_bit_identical_to_the_one_tile_kernel():
-    """csrc/conv_u8_pair.h (two pixel tiles per workgroup, the second one's frame rows prefetched into registers) against the
-    one-tile kernel it replaces for 84x84x4 stacks (-DISDQN_NO_U8_PAIR build of the same sources): parameters, Adam moments, losses,
+    """csrc/conv_u8_pair.h (first layer: two pixel tiles per workgroup, the second one's frame rows prefetched into registers) and
+    csrc/conv_s8_pair.h (second layer: two images per workgroup, the second one prefetched) against the one-tile / one-image kernels
+    they replace at the Nature geometry (-DISDQN_NO_U8_PAIR build of the same sources): parameters, Adam moments, losses,
     q-values, targets and priorities after three learn steps, the loss-only pass and a one-row forward of eight cnn shapes (c2 and c5
     at full size among them) hash to the same bits (scripts/r2/bits.py)."""
     import os
