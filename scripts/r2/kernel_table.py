@@ -38,7 +38,7 @@ a0, a1, a2 = 441 * 32, 121 * 64, 121 * 64          # activation elements per ima
 w0, w1, w2, wd, wh = 32 * 256, 64 * 512, 64 * 576, 7744 * 512, 512 * NHA
 model = [
     (r"conv_fwd_img_kernel<2, 2, true|conv_fwd_u8_pair_kernel<2", "conv0 fwd + LN + ReLU", 2 * B * 28224 + 2 * B * a0 * F4 + B * a0 * F4 + w0 * F4, 2 * 2 * B * 441 * 32 * 256, 2),
-    (r"conv_fwd_img_kernel<4, 3, false, 2", "conv1 fwd + LN + ReLU", 2 * B * a0 * F4 + 2 * B * a1 * F4 + B * a1 * F4 + w1 * F4, 2 * 2 * B * 121 * 64 * 512, 3),
+    (r"conv_fwd_img_kernel<4, 3, false, 2|conv_fwd_s8_pair_kernel", "conv1 fwd + LN + ReLU", 2 * B * a0 * F4 + 2 * B * a1 * F4 + B * a1 * F4 + w1 * F4, 2 * 2 * B * 121 * 64 * 512, 3),
     (r"conv_fwd_img_kernel<4, 3, false, 1", "conv2 fwd + LN + ReLU", 2 * B * a1 * F4 + 2 * B * a2 * F4 + B * a2 * F4 + w2 * F4, 2 * 2 * B * 121 * 64 * 576, 3),
     (r"PlainGemm<128, (128|64), 2, 2, false, false, 3, true, false, false", "dense0 fwd (split-K slabs)", 2 * B * a2 * F4 + wd * F4 + 2 * B * 512 * F4, 2 * 2 * B * 7744 * 512, 3),
     (r"head_chain_kernel", "hidden LN + head GEMM + TD + head dgrad + LN bwd", 2 * B * 512 * F4 * 2 + wh * F4 + B * 512 * F4, 2 * 2 * B * 512 * NHA + 2 * B * K * 512, 3),
