@@ -164,7 +164,7 @@ typedef struct isdqn_net_config {
                                            * halves: the backward then runs over all 2B rows (csrc/batchnorm.h, generic engine,
                                            * one stream).  forward / best_action(s) use the running averages (isdqn.py:130).
                                            * impala: also behind the ReLU of every residual block (dqn.py:29-30, module
-                                           * names "Stack_s/BatchNorm_b").  The *_target (DQN) and grad_on_batch / analysis entry points
+                                           * names "Stack_s/BatchNorm_b").  The *_target (DQN) and grad_on_batch entry points
                                            * return ISDQN_ERR_UNSUPPORTED with it (the reference's DQN cannot run with it either:
                                            * dqn.py:86 applies the network without a mutable batch_stats collection).          */
 } isdqn_net_config;
@@ -291,12 +291,15 @@ int isdqn_net_best_actions(const isdqn_net_config* cfg, const float* params, con
                            const int32_t* frame_ids, const float* obs, int32_t n_rows, const int32_t* idx_networks,
                            int32_t* out_actions, int32_t flags, void* workspace, void* stream);
 
-/* AnalysisNet.apply (slimdqn/utils/analysis_architecture.py:46-122) for the cnn / fc torsos with optional LayerNorm, as
- * eval_srank_and_dead_neurons uses it (experiments/base/srank_and_dead_neurons.py:8-22): the network without its last layer on
- * `n_rows` observations (<= 2 * batch_size).  features_out [n_rows][width of the last hidden layer] = its post-ReLU
- * activations; scores_out = for every hidden layer in order, the sum over the rows of its post-ReLU activations in the
- * reference's feature order ((H, W, C) flattened for conv layers) -- sizes from isdqn_net_analysis_layout.  The srank (an
- * SVD) and the dead-neuron fraction are host arithmetic on these two arrays, as in the reference (utils/analysis.py:4-17). */
+/* AnalysisNet.apply (slimdqn/utils/analysis_architecture.py:9-122) as eval_srank_and_dead_neurons uses it
+ * (experiments/base/srank_and_dead_neurons.py:8-22): the network without its last layer on `n_rows` observations
+ * (<= 2 * batch_size).  features_out [n_rows][width of the last hidden layer] = its post-ReLU activations (behind the last
+ * BatchNorm when the network has them, as the reference returns them); scores_out = for every recorded layer in the reference's
+ * order, the sum over the rows of its post-ReLU activations in the reference's feature order ((H, W, C) flattened for conv
+ * layers) -- cnn: the three conv layers, impala: the two ReLU outputs of each residual block of each Stack and the flattened
+ * torso output, then the hidden Dense layers; sizes from isdqn_net_analysis_layout (at most 32 entries).  BatchNorm networks
+ * run on the batch statistics of these rows (the reference applies AnalysisNet with mutable batch_stats).  The srank (an SVD)
+ * and the dead-neuron fraction are host arithmetic on these two arrays, as in the reference (utils/analysis.py:4-17). */
 int isdqn_net_analysis_layout(const isdqn_net_config* cfg, int32_t* n_hidden, int64_t* sizes, int32_t max_sizes);
 int isdqn_net_analysis(const isdqn_net_config* cfg, const float* params, const uint8_t* frames, int64_t frame_stride,
                        const int32_t* frame_ids, const float* obs, int32_t n_rows, float* features_out, float* scores_out,

@@ -2561,11 +2561,19 @@ extern "C" int isdqn_net_analysis_layout(const isdqn_net_config* cfg, int32_t* n
     if (!Pp) return rc;
     const Plan& P = *Pp;
     ISDQN_REQUIRE(n_hidden != nullptr, ISDQN_ERR_ARG, "null pointer");
-    *n_hidden = P.n_layers - 1;
-    for (int i = 0; i < P.n_layers - 1 && sizes != nullptr && i < max_sizes; ++i) {
+    int n = 0;
+    auto put = [&](int64_t v) {
+        if (sizes != nullptr && n < max_sizes) sizes[n] = v;
+        ++n;
+    };
+    if (P.L[0].kind == 2)  // impala: the two ReLU outputs of each residual block of each Stack (analysis_architecture.py:27-40)
+        for (int s = 0; s < IMP_STACKS; ++s)
+            for (int k = 0; k < 4; ++k) put((int64_t)P.imp[s].Hp * P.imp[s].Wp * P.imp[s].C);
+    for (int i = 0; i < P.n_layers - 1; ++i) {
         const Layer& l = P.L[i];
-        sizes[i] = l.kind != 1 ? (int64_t)l.npix * l.cout : (int64_t)l.out_f;
+        put(l.kind != 1 ? (int64_t)l.npix * l.cout : (int64_t)l.out_f);
     }
+    *n_hidden = n;
     return ISDQN_OK;
 }
 
@@ -2584,19 +2592,45 @@ extern "C" int isdqn_net_analysis(const isdqn_net_config* cfg, const float* para
     NetInput in{frames, frame_stride, frame_ids, 0, obs, nullptr, 0};
     float* ws = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
+    const bool x3 = cfg->precision == ISDQN_PRECISION_BF16X3;
     rc = refresh_mirror(P, params, ws, st);
     if (rc) return rc;
-    rc = net_forward(P, cfg->precision == ISDQN_PRECISION_BF16X3, params, in, n_rows, 0, ws, ws + P.q_off, st, P.n_layers - 1);
+    // BatchNorm networks: as the reference applies AnalysisNet (srank_and_dead_neurons.py:17: mutable batch_stats, use_running_average
+    // left False) -- the batch statistics of the analysed rows; the whole network runs (its head output is not used)
+    if (P.bn) rc = bn_forward(P, x3, params, in, n_rows, 0, ws, ws + P.q_off, /*running=*/false, st);
+    else rc = net_forward(P, x3, params, in, n_rows, 0, ws, ws + P.q_off, st, P.n_layers - 1);
     if (rc) return rc;
     int64_t off = 0;
+    auto rowsum = [&](const float* act_s8, int elems_p, int cpp, int c, int64_t width, float* feat) -> int {
+        hipLaunchKernelGGL(act_rowsum_kernel, dim3(ceil_div(elems_p, 256)), dim3(256), 0, st, act_s8, n_rows, elems_p, cpp, c, scores_out + off, feat,
+                           feat ? (int)width : 0);
+        ISDQN_HIP_CHECK(hipGetLastError());
+        off += width;
+        return ISDQN_OK;
+    };
+    if (P.L[0].kind == 2)
+        for (int s = 0; s < IMP_STACKS; ++s) {
+            const ImpalaStack& S = P.imp[s];
+            const int elems_p = S.Hp * S.Wp * S.C_p;
+            for (int b = 0; b < 2; ++b) {  // relu([LN](r)) in front of the block's BatchNorm, relu(conv) behind its first convolution
+                if ((rc = rowsum(ws + S.a1_off[b], elems_p, S.C_p, S.C, (int64_t)S.Hp * S.Wp * S.C, nullptr))) return rc;
+                if ((rc = rowsum(ws + S.a2_off[b], elems_p, S.C_p, S.C, (int64_t)S.Hp * S.Wp * S.C, nullptr))) return rc;
+            }
+        }
     for (int i = 0; i < P.n_layers - 1; ++i) {
         const Layer& l = P.L[i];
         const int cpp = l.kind != 1 ? l.cout_p : l.out_p, c = l.kind != 1 ? l.cout : l.out_f;
         const bool last = i == P.n_layers - 2;
-        hipLaunchKernelGGL(act_rowsum_kernel, dim3(ceil_div(l.out_elems_p, 256)), dim3(256), 0, st, ws + l.act_off, n_rows, l.out_elems_p,
-                           cpp, c, scores_out + off, last ? features_out : nullptr, last ? (l.kind != 1 ? l.npix * l.cout : l.out_f) : 0);
-        ISDQN_HIP_CHECK(hipGetLastError());
-        off += l.kind != 1 ? (int64_t)l.npix * l.cout : (int64_t)l.out_f;
+        const int64_t width = l.kind != 1 ? (int64_t)l.npix * l.cout : (int64_t)l.out_f;
+        // the sums are those of the ReLU output (in front of a BatchNorm); the feature matrix leaves the network behind the last
+        // BatchNorm (analysis_architecture.py:115-122): a second pass over that site's output, sums discarded into the head's q rows
+        if ((rc = rowsum(ws + l.act_off, l.out_elems_p, cpp, c, width, (last && !P.bn) ? features_out : nullptr))) return rc;
+        if (last && P.bn) {
+            const BnSite* b = bn_site_of(P, i);
+            hipLaunchKernelGGL(act_rowsum_kernel, dim3(ceil_div(l.out_elems_p, 256)), dim3(256), 0, st, (const float*)(ws + b->out_off), n_rows,
+                               l.out_elems_p, cpp, c, ws + P.slab_off, features_out, (int)width);
+            ISDQN_HIP_CHECK(hipGetLastError());
+        }
     }
     return ISDQN_OK;
 }

@@ -23,7 +23,7 @@ def _analysis_engine(eng: QNetEngine, n_rows: int) -> QNetEngine:
         _engines[key] = QNetEngine(
             eng.observation_dim, eng.n_actions, eng.n_heads, eng.features, eng.architecture_type, bool(c.layer_norm), (n_rows + 1) // 2,
             gamma_n=float(c.gamma_n), learning_rate=float(c.learning_rate), adam_eps=float(c.adam_eps), precision=eng.precision,
-            device=eng.device,
+            device=eng.device, batch_norm=eng.batch_norm,
         )
     return _engines[key]
 

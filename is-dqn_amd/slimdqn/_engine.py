@@ -378,11 +378,12 @@ class QNetEngine:
         return self.action_out
 
     def analysis(self, *, frames=None, frame_stride=0, frame_ids=None, obs=None, n_rows: int, params=None):
-        """AnalysisNet.apply (utils/analysis_architecture.py:46-122) on n_rows observations: (features [n_rows, width of the last
-        hidden layer], [per-layer sums over the rows of the post-ReLU activations, in the reference's shapes flattened])."""
+        """AnalysisNet.apply (utils/analysis_architecture.py:9-122) on n_rows observations: (features [n_rows, width of the last
+        hidden layer], [per-layer sums over the rows of the post-ReLU activations, in the reference's shapes flattened]).  impala:
+        the two ReLU outputs of every residual block come first; BatchNorm networks run on the batch statistics of these rows."""
         n_hidden = ctypes.c_int32()
-        sizes = (ctypes.c_int64 * 8)()
-        _hip.check(self.lib.isdqn_net_analysis_layout(ctypes.byref(self.cfg), ctypes.byref(n_hidden), sizes, 8))
+        sizes = (ctypes.c_int64 * 32)()  # (impala: 12 block activations + the torso output + the hidden Dense layers)
+        _hip.check(self.lib.isdqn_net_analysis_layout(ctypes.byref(self.cfg), ctypes.byref(n_hidden), sizes, 32))
         sizes = [int(sizes[i]) for i in range(n_hidden.value)]
         feats = torch.empty(n_rows, sizes[-1], dtype=torch.float32, device=self.device)
         scores = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)

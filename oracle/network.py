@@ -268,11 +268,15 @@ def _impala_stack(params, prefix: str, x: torch.Tensor, layer_norm: bool, captur
             q = params[f"{prefix}/LayerNorm_{b}"]
             x = _layer_norm(x, q["scale"], q["bias"])
         x = torch.relu(x)
+        if capture is not None:
+            capture[f"{prefix}/a1_{b}"] = x  # (AnalysisNet's Stack records the sums of both ReLU outputs of a block)
         if bn is not None:
             x = bn(x, f"{prefix}/BatchNorm_{b}")
         p = params[f"{prefix}/Conv_{1 + 2 * b}"]
         x = _conv_same(x, p["kernel"], p["bias"], 1)
         x = torch.relu(x)
+        if capture is not None:
+            capture[f"{prefix}/a2_{b}"] = x
         p = params[f"{prefix}/Conv_{2 + 2 * b}"]
         x = _conv_same(x, p["kernel"], p["bias"], 1)
         x = x + block_input
@@ -331,7 +335,10 @@ def forward(params, x, features, architecture_type: str, layer_norm: bool, captu
             q = params[f"LayerNorm_{n_ln}"]
             x = _layer_norm(x, q["scale"], q["bias"])
             n_ln += 1
-        x = bn(torch.relu(x).reshape(x.shape[0], -1), False)
+        x = torch.relu(x).reshape(x.shape[0], -1)
+        if capture is not None:
+            capture["ImpalaOut"] = x
+        x = bn(x, False)
         start = 3
     else:
         x = x.reshape(x.shape[0], -1)
