@@ -115,3 +115,41 @@ def test_analysis_flag_of_the_trainer_with_impala_and_batch_norm(tmp_path):
     logs = json.load(open(tmp_path / "atari" / "exp_output" / "anab_Synthetic" / "isdqn" / "analysis" / "1.json"))
     assert set(logs) == {"srank", "dead_neurons"} and len(logs["srank"]) >= 2
     assert all(1 <= s <= 16 for s in logs["srank"]) and all(0.0 <= d <= 1.0 for d in logs["dead_neurons"])
+
+
+@pytest.mark.parametrize("arch,ln,bn", [("cnn", True, False), ("cnn", False, True), ("impala", True, True), ("impala", False, False)])
+def test_reference_analysis_properties(arch, ln, bn):
+    """The reference's tests/test_analysis.py:41-81 on the HIP path (its random architecture / LayerNorm / BatchNorm draws as four fixed
+    cases): compute_srank of a constant matrix is 1 and of diag(0 .. n-1) the closed form; a freshly initialised network on 2550 random
+    states has a feature srank above 256 (of 512), srank 1 at threshold 1, fewer than 10 % dead neurons; with every kernel and bias
+    zeroed all neurons are dead."""
+    from slimdqn._engine import QNetEngine
+    from slimdqn.utils.analysis import compute_dead_neurons, compute_srank
+
+    n = 777
+    assert compute_srank(np.ones((n, 512))) == 1
+    assert compute_srank(np.diag(np.arange(0, n)).astype(np.float64)) == np.searchsorted(np.cumsum(np.arange(0, n)[::-1]), 0.99 * n * (n - 1) / 2, side="left") + 1
+
+    n_rows, obs, feats = 51 * 50, (84, 84, 4), (5, 7, 9, 512)
+    eng = QNetEngine(obs, 4, 3, feats, arch, ln, n_rows // 2, batch_norm=bn)
+    eng.init_params(3)
+    rng = np.random.default_rng(0)
+    # (the reference draws uniform [0, 1) floats: AnalysisNet divides by 255 like the Q-network; uint8 frames here, as the replay holds them)
+    states = rng.integers(0, 256, (n_rows,) + obs, dtype=np.uint8)
+    planes = torch.from_numpy(np.ascontiguousarray(np.moveaxis(states, -1, 1)).reshape(n_rows * obs[2], obs[0] * obs[1])).cuda()
+    ids = torch.arange(n_rows * obs[2], dtype=torch.int32, device="cuda")
+    feat, scores = eng.analysis(frames=planes, frame_stride=obs[0] * obs[1], frame_ids=ids, n_rows=n_rows)
+    feat = feat.cpu().numpy()
+    assert compute_srank(feat) > 256
+    assert compute_srank(feat, 1) == 1
+    # (the reference asserts < 0.1 for whatever architecture / normalisation it happened to draw; the un-normalised impala torso with
+    # 5 / 7 / 9 channels and zero biases starts with 16 % of its block units silent on these states -- the oracle's number too)
+    assert compute_dead_neurons([s.cpu().numpy() for s in scores]) < (0.1 if (ln or bn) else 0.3)
+    tree = eng.export_flax()
+    for mod, leaves in tree.items():
+        if "Conv" in mod or "Dense" in mod:
+            leaves["kernel"] = np.zeros_like(leaves["kernel"])
+            leaves["bias"] = np.zeros_like(leaves["bias"])
+    eng.import_flax(tree, batch_stats=eng.export_batch_stats() if bn else None)
+    _, scores0 = eng.analysis(frames=planes, frame_stride=obs[0] * obs[1], frame_ids=ids, n_rows=n_rows)
+    assert compute_dead_neurons([s.cpu().numpy() for s in scores0]) == 1
