@@ -349,3 +349,26 @@ def test_lunar_lander_entry_point_end_to_end(tmp_path):
     assert params["shared_parameters"]["features"] == [100, 100] and params["isdqn"]["n_bellman_iterations"] == 1
     model = pickle.load(open(out / "isdqn" / "models" / "1", "rb"))
     assert model["params"]["Dense_0"]["kernel"].shape == (8, 100) and model["params"]["Dense_2"]["kernel"].shape == (100, 2 * 4)
+
+
+@pytest.mark.parametrize("algo", ["dqn", "tfdqn", "isdqn"])
+def test_reference_atari_test_settings_on_the_synthetic_environment(tmp_path, algo):
+    """The reference's tests/test_atari.py:8-61 (and its isdqn / tfdqn siblings in tests/test_launch_job.py): the entry point with
+    features 2 3 1 15, batch 3, capacity 100, 10 training steps, an update every 3 steps.  ALE is not installed, so the emulator is the
+    seeded synthetic one (-env synthetic); everything behind it -- replay, one- to three-channel conv layers padded to 8, a 15-wide
+    dense layer, target updates every 3 steps -- is the device path."""
+    import importlib
+
+    run = importlib.import_module(f"experiments.atari.{algo}").run
+    argv = ["--experiment_name", f"_test_{algo}_Pong", "--seed", "1", "--disable_wandb", "--features", "2", "3", "1", "15",
+            "--replay_buffer_capacity", "100", "--batch_size", "3", "--update_horizon", "1", "--gamma", "0.99", "--learning_rate", "1e-4",
+            "--horizon", "10", "--n_epochs", "1", "--n_training_steps_per_epoch", "10", "--data_to_update", "3",
+            "--target_update_frequency", "3", "--n_initial_samples", "3", "--epsilon_end", "0.01", "--epsilon_duration", "4",
+            "--architecture_type", "cnn", "-env", "synthetic"]
+    run(argv, root=str(tmp_path))
+    out = tmp_path / "atari" / "exp_output" / f"_test_{algo}_Pong" / algo
+    res = json.load(open(out / "episode_returns_and_lengths" / "1.json"))
+    assert len(res["episode_returns"]) == 1
+    model = pickle.load(open(out / "models" / "1", "rb"))
+    assert model["params"]["Conv_2"]["kernel"].shape == (3, 3, 3, 1) and model["params"]["Dense_0"]["kernel"].shape == (11 * 11 * 1, 15)
+    assert all(np.isfinite(v).all() for leaves in model["params"].values() for v in leaves.values())

@@ -26,6 +26,10 @@ CONFIGS = [
     # 18 actions (full Atari set), B crossing no 64-row tile boundary evenly
     pytest.param(((32, 64, 64, 512), 4, 18, 33, True), id="a18-B33"),
     pytest.param(((32, 64, 64, 512), 3, 6, 10, False), id="headline-arch-noln"),
+    # the widths of the reference's own smoke test (tests/test_atari.py:25-29: features 2 3 1 15, batch 3): one- to three-channel
+    # conv layers inside 8-channel padding, LayerNorm over a single channel
+    pytest.param(((2, 3, 1, 15), 2, 3, 3, True), id="reference-smoke-widths-2-3-1-15-B3"),
+    pytest.param(((2, 3, 1, 15), 2, 3, 3, False), id="reference-smoke-widths-noln"),
 ]
 
 # Kernel instantiations that only large batches select (BASELINE configs[4]: B = 1024, K = 32, A = 4): the head chain
