@@ -1,12 +1,9 @@
-"""iS-DQN on LunarLander (BASELINE configs[0]: K=1, MLP torso [100, 100], uniform replay, batch 32) on the HIP engine.
+"""Target-free DQN on LunarLander (slimdqn/networks/tfdqn.py on the HIP engine, MLP torso).
 
-    python experiments/lunar_lander/isdqn.py -en test -s 1 -f 100 100 -nbi 1 ...
+    python experiments/lunar_lander/tfdqn.py -en test -s 1 -f 100 100 -at fc ...
 
-The reference ships the LunarLander wrapper (slimdqn/environments/lunar_lander.py:5-23) and tests that call
-``experiments/lunar_lander/*.py`` (tests/test_lunar_lander.py:18) but not the entry points themselves; this one follows
-experiments/atari/isdqn.py:15-48 with the fc architecture and stack size 1.  There is no CPU backend: the fc torso runs on the
-same HIP kernels as the Atari configurations (tests/test_gpu_network.py: test_fc_architecture_lunar_lander_shape).
-``-env synthetic`` replaces gymnasium's LunarLander-v3 (absent from the build image) by a seeded stand-in.
+The reference tests call this entry point (tests/test_lunar_lander.py:8-59) but its tree does not ship it; this one follows
+experiments/atari/tfdqn.py with the fc architecture and stack size 1 (experiments/lunar_lander/common.py).
 """
 import os
 import sys
@@ -20,22 +17,21 @@ import numpy as np
 from experiments.base.dqn import train
 from experiments.base.utils import prepare_logs
 from experiments.lunar_lander.common import make_environment, make_replay, seeds
-from slimdqn.networks.isdqn import iSDQN
+from slimdqn.networks.tfdqn import TFDQN
 
 
 def run(argvs=sys.argv[1:], root=None):
     from experiments.base import dist as replicas
 
     replicas.init_from_env()
-    p = prepare_logs("lunar_lander", "isdqn", argvs, root=root)
+    p = prepare_logs("lunar_lander", "tfdqn", argvs, root=root)
     q_seed, train_seed = seeds(p)
     env = make_environment(p)
     rb = make_replay(p)
-    agent = iSDQN(
+    agent = TFDQN(
         q_seed,
         env.observation_shape,
         env.n_actions,
-        n_bellman_iterations=p["n_bellman_iterations"],
         features=p["features"],
         layer_norm=p["layer_norm"],
         batch_norm=p["batch_norm"],
@@ -47,7 +43,6 @@ def run(argvs=sys.argv[1:], root=None):
         target_update_frequency=p["target_update_frequency"],
         batch_size=p["batch_size"],
         precision=p["precision"],
-        huber_delta=p["huber_delta"],
     )
     out = train(np.random.default_rng(train_seed), p, agent, env, rb)
     replicas.finalize()

@@ -372,3 +372,22 @@ def test_reference_atari_test_settings_on_the_synthetic_environment(tmp_path, al
     model = pickle.load(open(out / "models" / "1", "rb"))
     assert model["params"]["Conv_2"]["kernel"].shape == (3, 3, 3, 1) and model["params"]["Dense_0"]["kernel"].shape == (11 * 11 * 1, 15)
     assert all(np.isfinite(v).all() for leaves in model["params"].values() for v in leaves.values())
+
+
+@pytest.mark.parametrize("algo", ["dqn", "tfdqn", "isdqn"])
+def test_reference_lunar_lander_test_settings(tmp_path, algo):
+    """The reference's tests/test_lunar_lander.py:8-59: experiments/lunar_lander/<algo>.py with features 25 15, batch 3, capacity 100,
+    10 training steps, fc.  (gymnasium is not installed: the seeded synthetic LunarLander stands in for the emulator.)"""
+    import importlib
+
+    run = importlib.import_module(f"experiments.lunar_lander.{algo}").run
+    argv = ["--experiment_name", f"_test_{algo}", "--seed", "1", "--disable_wandb", "--features", "25", "15", "--replay_buffer_capacity", "100",
+            "--batch_size", "3", "--update_horizon", "1", "--gamma", "0.99", "--learning_rate", "1e-4", "--horizon", "10", "--n_epochs", "1",
+            "--n_training_steps_per_epoch", "10", "--data_to_update", "3", "--target_update_frequency", "3", "--n_initial_samples", "3",
+            "--epsilon_end", "0.01", "--epsilon_duration", "4", "--architecture_type", "fc", "-env", "synthetic"]
+    run(argv, root=str(tmp_path))
+    out = tmp_path / "lunar_lander" / "exp_output" / f"_test_{algo}" / algo
+    assert len(json.load(open(out / "episode_returns_and_lengths" / "1.json"))["episode_returns"]) == 1
+    model = pickle.load(open(out / "models" / "1", "rb"))
+    assert model["params"]["Dense_0"]["kernel"].shape == (8, 25) and model["params"]["Dense_1"]["kernel"].shape == (25, 15)
+    assert all(np.isfinite(v).all() for leaves in model["params"].values() for v in leaves.values())
