@@ -48,8 +48,9 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--gpus", type=int, default=1, help="processes to start = GPUs used (GPU i -> rank i)")
     ap.add_argument("--games", nargs="+", default=["Asterix"])
-    ap.add_argument("--first_seed", type=int, default=1)
-    ap.add_argument("--n_seeds", type=int, default=1)
+    ap.add_argument("--first_seed", type=int, default=None)
+    ap.add_argument("--n_seeds", type=int, default=None, help="seeds per game (default 1)")
+    ap.add_argument("--last_seed", type=int, default=None, help="the reference launchers' spelling: n_seeds = last_seed - first_seed + 1")
     ap.add_argument("--algo", default="isdqn")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--no-gpu-pinning", action="store_true", help="do not set HIP_VISIBLE_DEVICES (CPU-only / gloo runs)")
@@ -58,6 +59,26 @@ def main(argv=None) -> int:
     ap.add_argument("rest", nargs=argparse.REMAINDER, help="-- followed by the trainer's own flags (-en without the game suffix)")
     args = ap.parse_args(argv)
     rest = args.rest[1:] if args.rest[:1] == ["--"] else args.rest
+    # The checks of the reference's shell launchers (launch_job/*/normal/local_*.sh via parse_arguments.sh; tests/test_launch_job.py:4-37),
+    # before any process is started: an experiment name, a first seed, a non-empty seed range.
+    def refuse(msg):
+        print(f"[launch] {msg}", file=sys.stderr, flush=True)
+        return 2
+
+    if args.module is None and not any(f in rest for f in ("-en", "--experiment_name")):
+        return refuse("the experiment name is not specified (-- -en <name> ...)")
+    if args.first_seed is None:
+        return refuse("the first seed is not specified (--first_seed)")
+    if args.last_seed is not None and args.n_seeds is not None and args.n_seeds != args.last_seed - args.first_seed + 1:
+        return refuse("--n_seeds and --last_seed disagree")
+    if args.last_seed is not None:
+        if args.last_seed < args.first_seed:
+            return refuse("the last seed should be greater than or equal to the first seed")
+        args.n_seeds = args.last_seed - args.first_seed + 1
+    if args.n_seeds is None:
+        args.n_seeds = 1
+    if args.n_seeds < 1 or args.gpus < 1:
+        return refuse("--n_seeds and --gpus must be at least 1")
     port = free_port()
     entry = args.module or os.path.join(_HERE, "atari", f"{args.algo}.py")
     procs = []

@@ -87,3 +87,14 @@ def test_bench_steps_per_graph_divides_timed_and_warmup_steps():
     assert bench.steps_per_graph(20, 5, 8) == 5      # the driver's --steps 20 --warmup 5: exactly 20 timed, 5 warm-up
     assert bench.steps_per_graph(4000, 4000, 8) == 8
     assert bench.steps_per_graph(7, 0, 8) == 7 and bench.steps_per_graph(20, 3, 8) == 1
+
+
+def test_launcher_refuses_incomplete_arguments_before_starting_anything():
+    """The reference's tests/test_launch_job.py:4-37 on experiments/launch.py: no experiment name, no first seed, a last seed below the
+    first one -- every case ends with a non-zero status (and no child process: the refusals come before the first Popen)."""
+    from experiments import launch
+
+    assert launch.main([]) > 0                                                                    # no experiment name
+    assert launch.main(["--", "-en", "_test_launch_local"]) > 0                                   # no first seed
+    assert launch.main(["--first_seed", "10", "--last_seed", "1", "--", "-en", "_test_launch_local"]) > 0  # empty seed range
+    assert launch.main(["--first_seed", "1", "--last_seed", "3", "--n_seeds", "2", "--", "-en", "_test_launch_local"]) > 0
