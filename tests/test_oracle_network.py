@@ -187,3 +187,20 @@ def test_impala_torso_restatement_against_plain_numpy_loops():
     t = np.maximum(ln(t @ P["Dense_0"]["kernel"] + P["Dense_0"]["bias"], P["LayerNorm_1"]), 0.0)
     want = t @ P["Dense_1"]["kernel"] + P["Dense_1"]["bias"]
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10)
+
+
+def test_per_sample_statement_of_the_loss_agrees_with_the_batched_one():
+    """tests/flops_computation/isdqn.py:93-100 states the loss a second time, per sample under vmap: q = heads 1..K of the state at the
+    taken action, targets from heads 0..K-1 of the next state (stop-gradient), sum_k of the squared errors, mean over the batch --
+    the same number as isdqn.py:92-103's batched td.mean(0).sum().  Both statements, evaluated on the oracle's network."""
+    ag = _agent(K=3, A=4)
+    batch = _batch(5, 4, seed=2)
+    batched, _ = ag.loss_on_batch(ag.params, batch)
+    per_sample = []
+    for b in range(5):
+        q_s = ag.apply(ag.params, torch.as_tensor(batch.state[b])[None])[0]          # (1+K, A)
+        q_n = ag.apply(ag.params, torch.as_tensor(batch.next_state[b])[None])[0]
+        q = q_s[1:, int(batch.action[b])]
+        target = float(batch.reward[b]) + (1 - int(batch.is_terminal[b])) * ag.gamma**ag.update_horizon * q_n[:-1].max(dim=-1).values
+        per_sample.append(((q - target.detach()) ** 2).sum())
+    assert abs(float(torch.stack(per_sample).mean()) - float(batched)) < 1e-10 * max(1.0, abs(float(batched)))
