@@ -38,6 +38,33 @@ def test_graph_replay_equals_eager_steps(workload):
     assert not torch.equal(fresh.eng.params, graphed.eng.params)
 
 
+def test_trusted_graph_only_while_the_mirror_is_current():
+    """GraphedUpdate holds two captures: one that rebuilds the weight mirror at its head and one that takes it as is, replayed
+    only while the engine's bookkeeping (_engine.py: _mirror_is_current) says nothing wrote the parameters since the last replay.
+    A torch-side write and a head shift between replays must both be seen by the next replay."""
+    S = 3
+    eager, graphed = _replica("c2"), _replica("c2")
+    graphed.enable_graph(S)
+    g = graphed.graphed
+    used = []
+    for replay in range(5):
+        if replay == 2:  # a writer the version counter sees
+            for r in (eager, graphed):
+                r.eng.params.mul_(1.0009765625)
+        if replay == 4:  # a writer inside the library
+            for r in (eager, graphed):
+                r.eng.shift_params()
+        used.append(graphed.eng._mirror_is_current(None))
+        for _ in range(S):
+            eager.step()
+        g.run()
+    torch.cuda.synchronize()
+    assert used == [False, True, False, True, False]
+    for name in ("params", "adam_m", "adam_v", "adam_count", "losses_accum"):
+        a, b = getattr(eager.eng, name), getattr(graphed.eng, name)
+        assert torch.equal(a, b), f"{name}: {(a != b).sum().item()} elements differ between eager and graph replay"
+
+
 @pytest.mark.parametrize("prioritized", [False, True])
 def test_agent_update_online_params_graphed_equals_eager(prioritized):
     """The drop-in trainer gets the captured step: `iSDQN.update_online_params` on a device replay replays a one-step
