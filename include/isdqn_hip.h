@@ -164,9 +164,12 @@ typedef struct isdqn_net_config {
                                            * halves: the backward then runs over all 2B rows (csrc/batchnorm.h, generic engine,
                                            * one stream).  forward / best_action(s) use the running averages (isdqn.py:130).
                                            * impala: also behind the ReLU of every residual block (dqn.py:29-30, module
-                                           * names "Stack_s/BatchNorm_b").  The *_target (DQN) and grad_on_batch entry points
-                                           * return ISDQN_ERR_UNSUPPORTED with it (the reference's DQN cannot run with it either:
-                                           * dqn.py:86 applies the network without a mutable batch_stats collection).          */
+                                           * names "Stack_s/BatchNorm_b").  grad_on_batch runs with it (the analysis agents,
+                                           * analysisdqn.py:162-219; with `target_params` the two halves are two forwards on
+                                           * their own statistics and the backward covers the B state rows).  The *_target
+                                           * learn / loss entry points (DQN) return ISDQN_ERR_UNSUPPORTED with it: the reference's
+                                           * DQN cannot run with it either (dqn.py:86 applies the network without a mutable
+                                           * batch_stats collection).                                                           */
 } isdqn_net_config;
 
 /* One parameter tensor inside the flat fp32 parameter buffer.  `name` is the Flax
@@ -263,6 +266,13 @@ int isdqn_net_learn_on_batch_target(const isdqn_net_config* cfg, float* params, 
 int isdqn_net_loss_on_batch_target(const isdqn_net_config* cfg, const float* params, const float* target_params,
                                    const isdqn_batch* batch, float* losses, float* q_values, float* targets,
                                    void* workspace, void* stream);
+
+/* BatchNorm networks: params["batch_stats"] <- the batch_stats collection returned by the LAST training-mode forward that ran
+ * in `workspace` (learn / loss / grad_on_batch; flax: apply(..., mutable=["batch_stats"])), i.e. running = 0.99 * running +
+ * 0.01 * (that forward's batch statistics).  learn_on_batch does this itself for its own forward (isdqn.py:87-88); the analysis
+ * agents store the collection of ANOTHER forward -- the evaluation batch's, analysisdqn.py:121-131, analysistfdqn.py:85-95 -- and
+ * call this behind that loss pass.  ISDQN_ERR_ARG for a configuration without batch_norm. */
+int isdqn_net_bn_commit_running(const isdqn_net_config* cfg, float* params, const void* workspace, void* stream);
 
 /* Gradient of a TD loss, no update: the three gradients AnalysisDQN compares (slimdqn/networks/analysisdqn.py:156-219 --
  * jax.grad of compute_loss_is / compute_loss_tf / compute_loss_tb).  `grad_out` receives the gradient w.r.t. every parameter

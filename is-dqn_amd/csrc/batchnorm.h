@@ -323,14 +323,28 @@ static int bn_forward(const Plan& P, bool x3, const float* params, const NetInpu
 }
 
 // learn_on_batch / loss_on_batch with BatchNorm (isdqn.py:82-103, tfdqn.py:58-80): see the header of this file
+// `sel`: the heads a gradient-only pass regresses (analysisdqn.py:162-183).  `target_params` (gradient-only passes: compute_loss_tb,
+// analysisdqn.py:165-173): the next states go through them in a forward of their own B rows -- on THEIR batch statistics -- and the
+// states through `params` on the statistics of the B state rows; the backward then runs over those B rows only.
 static int bn_learn_or_loss(const isdqn_net_config* cfg, const Plan& P, float* params, float* adam_m, float* adam_v, int32_t* adam_count,
                             const isdqn_batch* batch, float* losses, float* loss_accum, float* q_values, float* targets, double* priorities,
-                            float* ws, hipStream_t st, bool learn, float* grad_out, bool update) {
+                            float* ws, hipStream_t st, bool learn, float* grad_out, bool update, const float* target_params, const HeadSel* sel) {
     const bool x3 = cfg->precision == ISDQN_PRECISION_BF16X3;
-    const int B = P.B, N2 = P.N2, K = P.K;
+    const int B = P.B, N2 = P.N2, K = sel ? sel->K : P.K;
+    const int on0 = sel ? sel->on0 : P.oh, tg0 = sel ? sel->tg0 : 0;
+    if (sel) ISDQN_REQUIRE(sel->K >= 1 && on0 >= 0 && tg0 >= 0 && on0 + K <= P.n_heads && tg0 + K <= P.n_heads && K <= P.K, ISDQN_ERR_ARG,
+                           "head selection outside the network's heads");
     int rc;
     NetInput in{batch->frames, batch->frame_stride, batch->frame_ids, B, batch->state, batch->next_state, B};
-    if (cfg->arch == ISDQN_ARCH_FC) {
+    if (target_params != nullptr) {
+        const int stack = cfg->arch != ISDQN_ARCH_FC ? cfg->obs_c : 0;
+        NetInput nx{batch->frames, batch->frame_stride, batch->frame_ids, 0, batch->next_state, nullptr, 0, 2 * stack, stack};
+        rc = refresh_mirror(P, target_params, ws, st);
+        if (rc) return rc;
+        rc = bn_forward(P, x3, target_params, nx, B, 0, ws, ws + P.q_off + (int64_t)B * P.nha_p, /*running=*/false, st);
+        if (rc) return rc;
+        in = NetInput{batch->frames, batch->frame_stride, batch->frame_ids, 0, batch->state, nullptr, 0, 2 * stack, 0};
+    } else if (cfg->arch == ISDQN_ARCH_FC) {
         // the 2B observation rows as ONE matrix: the first layer's weight gradient contracts over all of them
         const int64_t n = (int64_t)B * P.L[0].in_f;
         float* cat = ws + P.x0_off;
@@ -338,12 +352,13 @@ static int bn_learn_or_loss(const isdqn_net_config* cfg, const Plan& P, float* p
         ISDQN_HIP_CHECK(hipMemcpyAsync(cat + n, batch->next_state, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         in.obs = cat; in.obs2 = nullptr; in.obs_split = 0;
     }
-    if (!(batch->flags & ISDQN_BATCH_MIRROR_CURRENT)) {
+    if (target_params != nullptr || !(batch->flags & ISDQN_BATCH_MIRROR_CURRENT)) {
         rc = refresh_mirror(P, params, ws, st);
         if (rc) return rc;
     }
     const float* wmir = ws + P.wsplit_off;
-    rc = bn_forward(P, x3, params, in, N2, learn ? N2 : 0, ws, ws + P.q_off, /*running=*/false, st);
+    const int Bb = target_params ? B : N2;  // rows of the forward the gradient flows through
+    rc = bn_forward(P, x3, params, in, Bb, learn ? Bb : 0, ws, ws + P.q_off, /*running=*/false, st);
     if (rc) return rc;
 
     // ---- targets, loss, dL/dq (rows [0, B); the next-state rows of dL/dq are zero: stop_gradient, isdqn.py:99) ----
@@ -352,7 +367,7 @@ static int bn_learn_or_loss(const isdqn_net_config* cfg, const Plan& P, float* p
     const int n_blk = ceil_div(B, TD_ROWS);
     float* loss_part = ws + P.lpart_off;
     float* dbh_part = loss_part + (int64_t)n_blk * K;
-    hipLaunchKernelGGL(td_kernel, dim3(n_blk), dim3(256), 2 * TD_ROWS * K * sizeof(float), st, ws + P.q_off, B, K, P.oh, 0, P.n_actions, P.nha_p,
+    hipLaunchKernelGGL(td_kernel, dim3(n_blk), dim3(256), 2 * TD_ROWS * K * sizeof(float), st, ws + P.q_off, B, K, on0, tg0, P.n_actions, P.nha_p,
                        batch->action, batch->reward, batch->terminal, cfg->gamma_n, cfg->huber_delta, learn ? ws + P.dout_off : nullptr, qv, tg, priorities,
                        loss_part, dbh_part);
     ISDQN_HIP_CHECK(hipGetLastError());
@@ -362,7 +377,7 @@ static int bn_learn_or_loss(const isdqn_net_config* cfg, const Plan& P, float* p
     ISDQN_HIP_CHECK(hipGetLastError());
     if (batch->priorities_ready != nullptr) ISDQN_HIP_CHECK(hipEventRecord((hipEvent_t)batch->priorities_ready, st));
     if (!learn) return ISDQN_OK;
-    {
+    if (Bb > B) {
         const int64_t n = (int64_t)(N2 - B) * P.nha_p;
         hipLaunchKernelGGL(bn_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws + P.dout_off + (int64_t)B * P.nha_p, n);
         ISDQN_HIP_CHECK(hipGetLastError());
@@ -375,7 +390,6 @@ static int bn_learn_or_loss(const isdqn_net_config* cfg, const Plan& P, float* p
         e.p_off = p_off; e.size = size; e.g = g; e.n_slabs = n_slabs; e.slab_stride = stride; e.block_start = 0;
         entries.push_back(e);
     };
-    const int Bb = N2;
     float* da = ws + P.da_off;
     const float* dz_cur = ws + P.dout_off;
     int dz_ld = P.nha_p;
@@ -477,5 +491,17 @@ static int bn_learn_or_loss(const isdqn_net_config* cfg, const Plan& P, float* p
                                (const float*)(ws + b.bmean_off), (const float*)(ws + b.bvar_off), b.G);
             ISDQN_HIP_CHECK(hipGetLastError());
         }
+    return ISDQN_OK;
+}
+
+// params["batch_stats"] = the batch_stats collection the LAST training-mode forward in this workspace returned (flax: mutable=["batch_stats"]):
+// the analysis agents keep the collection of a forward that is not the learn step's own (analysisdqn.py:121-131, analysistfdqn.py:85-95).
+static int bn_commit_running(const Plan& P, float* params, const float* ws, hipStream_t st) {
+    for (int s = 0; s < P.n_bn; ++s) {
+        const BnSite& b = P.bns[s];
+        hipLaunchKernelGGL(bn_running_kernel, dim3(ceil_div(b.G, 256)), dim3(256), 0, st, params + b.mean_off, params + b.var_off, ws + b.bmean_off,
+                           ws + b.bvar_off, b.G);
+        ISDQN_HIP_CHECK(hipGetLastError());
+    }
     return ISDQN_OK;
 }

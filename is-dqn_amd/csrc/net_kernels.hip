@@ -1731,6 +1731,12 @@ static int conv_wgrad_slabs(const Layer& l, int n_img) {
 static inline const BnSite* bn_site_of(const Plan& P, int layer);
 static int bn_site_forward(const BnSite& b, const float* params, float* ws, int rows, bool running, hipStream_t st);
 static int bn_site_backward(const BnSite& b, const float* params, float* ws, float* dy, int rows, bool apply, hipStream_t st);
+// Which heads a loss regresses (default: the plan's iterated pairs, online head oh + k on target head k, k < K).  The analysis
+// agents evaluate single-pair losses on the multi-head network: online head 1 on target head 1 (analysisdqn.py:156-183).
+struct HeadSel {
+    int on0, tg0, K;
+};
+
 #include "impala.h"
 #include "batchnorm.h"
 
@@ -1896,12 +1902,6 @@ extern "C" int isdqn_net_forward(const isdqn_net_config* cfg, const float* param
     return ISDQN_OK;
 }
 
-// Which heads a loss regresses (default: the plan's iterated pairs, online head oh + k on target head k, k < K).  The analysis
-// agents evaluate single-pair losses on the multi-head network: online head 1 on target head 1 (analysisdqn.py:156-183).
-struct HeadSel {
-    int on0, tg0, K;
-};
-
 // Side stream for the weight gradients.  The backward's critical path is dgrad -> LayerNorm-backward -> dgrad ...;
 // every weight gradient only needs its layer's dz and is needed again by Adam at the very end, so they run on a
 // second HIP stream and share the CUs with the data-gradient chain (both sides are partly latency bound and
@@ -1962,10 +1962,11 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         adam_v = params;
     }
     if (P.bn) {  // BatchNorm: the layer-by-layer form over all 2B rows (batchnorm.h)
-        ISDQN_REQUIRE(target_params == nullptr && sel == nullptr && (!learn || update), ISDQN_ERR_UNSUPPORTED,
-                      "BatchNorm networks: learn_on_batch / loss_on_batch only (the reference's DQN cannot run with batch_norm either, dqn.py:86)");
+        ISDQN_REQUIRE(target_params == nullptr || (learn && !update), ISDQN_ERR_UNSUPPORTED,
+                      "BatchNorm networks: separate target parameters only in gradient-only passes (the reference's DQN cannot run with "
+                      "batch_norm, dqn.py:86)");
         return bn_learn_or_loss(cfg, P, params, adam_m, adam_v, adam_count, batch, losses, loss_accum, q_values, targets, priorities,
-                                (float*)workspace, (hipStream_t)stream, learn, grad_out, update);
+                                (float*)workspace, (hipStream_t)stream, learn, grad_out, update, target_params, sel);
     }
     const bool x3 = cfg->precision == ISDQN_PRECISION_BF16X3;
     const int B = P.B, K = sel ? sel->K : P.K;
@@ -2470,6 +2471,15 @@ extern "C" int isdqn_net_grad_on_batch(const isdqn_net_config* cfg, const float*
     HeadSel sel{online_head, target_head, n_pairs};
     return learn_or_loss(cfg, const_cast<float*>(params), nullptr, nullptr, nullptr, batch, losses, nullptr, q_values, targets, nullptr,
                          workspace, stream, true, grad_out, target_params, n_pairs > 0 ? &sel : nullptr, false);
+}
+
+extern "C" int isdqn_net_bn_commit_running(const isdqn_net_config* cfg, float* params, const void* workspace, void* stream) {
+    int rc;
+    const Plan* Pp = cached_plan(cfg, &rc);
+    if (!Pp) return rc;
+    ISDQN_REQUIRE(params != nullptr && workspace != nullptr, ISDQN_ERR_ARG, "null pointer");
+    ISDQN_REQUIRE(Pp->bn, ISDQN_ERR_ARG, "not a BatchNorm network");
+    return bn_commit_running(*Pp, params, (const float*)workspace, (hipStream_t)stream);
 }
 
 // DQN.learn_on_batch / loss_on_batch (dqn.py:59-83): separate target parameters for the next states.

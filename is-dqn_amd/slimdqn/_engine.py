@@ -360,6 +360,19 @@ class QNetEngine:
         self._mirror_holds(params)
         return self.losses
 
+    def commit_batch_stats(self) -> None:
+        """params["batch_stats"] <- the collection the last training-mode forward in this workspace returned (the analysis agents keep
+        the evaluation batch's: analysisdqn.py:121-131)."""
+        _hip.check(self.lib.isdqn_net_bn_commit_running(ctypes.byref(self.cfg), _hip.ptr(self.params), _hip.ptr(self.workspace),
+                                                        _hip.stream_ptr(self.device)), "isdqn_net_bn_commit_running")
+
+    def batch_stats_slice(self) -> slice:
+        """Where the running averages (tensor kinds 7, 8) sit in the flat parameter buffer: one contiguous block behind the optimised ones."""
+        stats = [i for i in self.infos if i.kind in (7, 8)]
+        lo, hi = min(i.offset for i in stats), max(i.offset + i.size for i in stats)
+        assert all(i.offset + i.size <= lo or i.offset >= hi for i in self.infos if i.kind not in (7, 8)), "running averages are not contiguous"
+        return slice(lo, hi)
+
     def shift_params(self, params=None) -> None:
         p = self.params if params is None else params
         _hip.check(self.lib.isdqn_net_shift_params(ctypes.byref(self.cfg), _hip.ptr(p), _hip.stream_ptr(self.device)))

@@ -23,9 +23,6 @@ class AnalysisDQN(iSDQN):
     def __init__(self, *args, **kwargs):
         kwargs["use_graph"] = False  # every update reads diagnostics back: nothing to capture
         super().__init__(*args, **kwargs)
-        if self.batch_norm:
-            raise NotImplementedError("the analysis agents are not built for BatchNorm networks (gradient-only and loss passes with "
-                                      "separate target parameters: include/isdqn_hip.h, batch_norm)")
         self.target_params = self.params.clone()  # analysisdqn.py:49
         K = self.n_bellman_iterations
         self.cumulated_target_churns_train = np.zeros(K)
@@ -125,7 +122,15 @@ class AnalysisDQN(iSDQN):
         eng.grad_on_batch(cb, g_tf, online_head=1, target_head=1, n_pairs=1)
         eng.loss_on_batch(cb_eval)
         eval_pre = eng.targets.clone()
+        if self.batch_norm:
+            # the collection the reference stores with the updated parameters is the one its LAST forward before the update returned:
+            # the evaluation batch's (analysisdqn.py:121 overwrites `batch_stats`, :130-131 stores it) -- not the training batch's
+            stats = eng.batch_stats_slice()
+            eng.commit_batch_stats()
+            eval_stats = eng.params[stats].clone()
         losses = eng.learn_on_batch(cb, grad_out=g_is).clone()  # the iS-DQN step; its gradient is the third one
+        if self.batch_norm:
+            eng.params[stats] = eval_stats
         train_pre = eng.targets.clone()
         eng.loss_on_batch(cb)
         churn_train = (train_pre - eng.targets).abs().mean(dim=0)

@@ -9,9 +9,6 @@ from slimdqn.networks.tfdqn import TFDQN
 class AnalysisTFDQN(TFDQN):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        if self.batch_norm:
-            raise NotImplementedError("the analysis agents are not built for BatchNorm networks (gradient-only and loss passes with "
-                                      "separate target parameters: include/isdqn_hip.h, batch_norm)")
         self.cumulated_target_churn_train = 0.0
         self.cumulated_target_churn_eval = 0.0
 
@@ -45,7 +42,13 @@ class AnalysisTFDQN(TFDQN):
         cb, cb_eval = self._c_batch(eng, batch_samples), self._c_batch(eng, batch_samples_eval)
         eng.loss_on_batch(cb_eval)
         eval_pre = eng.targets.clone()
+        if self.batch_norm:  # the stored collection is the evaluation forward's (analysistfdqn.py:85-95), as in AnalysisDQN
+            stats = eng.batch_stats_slice()
+            eng.commit_batch_stats()
+            eval_stats = eng.params[stats].clone()
         loss = eng.learn_on_batch(cb)[0].clone()
+        if self.batch_norm:
+            eng.params[stats] = eval_stats
         train_pre = eng.targets.clone()
         eng.loss_on_batch(cb)
         churn_train = (train_pre - eng.targets).abs().mean()

@@ -5,6 +5,8 @@ numerics (oracle/network.py).  Follows the reference ``slimdqn/networks/analysis
   * update_online_params (TWO batches per update: train, then eval) ........ :63-84
   * update_target_params (target copy BEFORE the head shift, log names) .... :86-121
   * learn_on_batch (targets of both batches before / after the update) ..... :123-160
+      - batch_norm: every apply is a training-mode forward (mutable batch_stats, :40-42); the collection stored with the updated
+        parameters is the evaluation batch's pre-update forward's (:121, :130-131)
   * grad_and_loss_on_batch ................................................ :162-219
       - loss_tb: head 1 of the states (params) on head 1 of the next states through params_target
       - loss_tf: head 1 on head 1 of the same parameters (stop-gradient)
@@ -19,6 +21,10 @@ import torch
 
 from oracle import network as net
 from oracle.isdqn import iSDQN
+
+
+def _detached(stats, dtype):
+    return {m: {n: t.detach().to(dtype) for n, t in l.items()} for m, l in stats.items()}
 
 
 class AnalysisDQN(iSDQN):
@@ -121,7 +127,12 @@ class AnalysisDQN(iSDQN):
         g_is, g_tf, g_tb = self.three_gradients(params, params_target, batch)
         f_is, f_tf, f_tb = (self.feature_gradient(g) for g in (g_is, g_tf, g_tb))
         train_pre, eval_pre = self._targets(params, batch), self._targets(params, batch_eval)
+        # batch_norm: the collection stored with the new parameters is the one the LAST forward before the update returned -- the
+        # evaluation batch's (analysisdqn.py:121 rebinds `batch_stats`, :130-131 stores it), not the training forward's
+        eval_stats = _detached(self._new_stats, self.dtype) if self.batch_norm else None
         new_params, new_state, losses = iSDQN.learn_on_batch(self, params, optimizer_state, batch)
+        if self.batch_norm:
+            self.batch_stats = eval_stats
         train_post, eval_post = self._targets(new_params, batch), self._targets(new_params, batch_eval)
         return (new_params, new_state, losses, (train_pre - train_post).abs().mean(0).numpy().astype(np.float64),
                 (eval_pre - eval_post).abs().mean(0).numpy().astype(np.float64), self.cosine(f_is, f_tb), self.cosine(f_tf, f_tb))
@@ -139,6 +150,9 @@ class AnalysisTFDQN:
         a = self.agent
         targets = lambda p, s: a.loss_terms(p, s)[1].detach()
         train_pre, eval_pre = targets(params, batch), targets(params, batch_eval)
+        eval_stats = _detached(a._new_stats, a.dtype) if a.batch_norm else None  # (analysistfdqn.py:85-95: the evaluation forward's collection)
         new_params, new_state, loss = a.learn_on_batch(params, optimizer_state, batch)
+        if a.batch_norm:
+            a.batch_stats = eval_stats
         return (new_params, new_state, loss, float((train_pre - targets(new_params, batch)).abs().mean()),
                 float((eval_pre - targets(new_params, batch_eval)).abs().mean()))

@@ -100,7 +100,7 @@ def run_case(name, arch, obs, feats, K, A, B, ln=True, bn=False, target=False, g
         eng.best_actions(obs=fwd["obs"][:nrow].contiguous() if False else fwd["obs"], idx_networks=heads)
     else:
         eng.best_actions(frames=fwd["frames"], frame_stride=fwd["frame_stride"], frame_ids=fwd["frame_ids"], idx_networks=heads)
-    if grad and not bn:
+    if grad:  # (BatchNorm networks too: the analysis agents' gradient-only passes, with and without separate target parameters)
         eng.grad_on_batch(batch, grad_out)
         if K >= 1 and n_heads >= 2:
             eng.grad_on_batch(batch, grad_out, target_params=tparams, online_head=1, target_head=1, n_pairs=1)

@@ -189,7 +189,8 @@ def test_unbuilt_batchnorm_combinations_raise():
     with pytest.raises(Exception):  # the DQN form (separate target parameters) does not exist with BatchNorm -- in the reference either
         eng.learn_on_batch_target(batch, eng.params.clone())
     with pytest.raises(Exception):
-        eng.grad_on_batch(batch, torch.zeros_like(eng.params))
+        eng.loss_on_batch_target(batch, eng.params.clone())
+    # (the gradient-only pass takes separate target parameters: the analysis agents, tests/test_gpu_analysis_agents.py)
 
 
 def test_agent_with_batchnorm_trains_acts_and_exports_like_the_oracle_agent():
