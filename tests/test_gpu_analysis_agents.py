@@ -137,7 +137,7 @@ def _bn_pair(arch, K, A, B):
     from slimdqn.networks.analysisdqn import AnalysisDQN
     from tests.gpu_helpers import make_frame_batch, perturbed_params
 
-    obs, feats = ((84, 84, 4), [8, 12, 16, 24]) if arch == "cnn" else ((8,), [24, 40])
+    obs, feats = {"cnn": ((84, 84, 4), [8, 12, 16, 24]), "impala": ((36, 36, 2), [16, 8, 16, 24]), "fc": ((8,), [24, 40])}[arch]
     params = perturbed_params(4, obs, feats, arch, (1 + K) * A, True, batch_norm=True)
     rng = np.random.default_rng(2)
     stats = {m: {"mean": rng.normal(0, 0.3, l["mean"].shape).astype(np.float32), "var": rng.uniform(0.5, 2.0, l["var"].shape).astype(np.float32)}
@@ -152,8 +152,8 @@ def _bn_pair(arch, K, A, B):
     ora.target_params = onet.to_torch(bumped, torch.float64)
     batches = []
     for seed in (11, 12):
-        if arch == "cnn":
-            batches.append(make_frame_batch(B, A, seed=seed)[5])
+        if arch != "fc":
+            batches.append(make_frame_batch(B, A, seed=seed, h=obs[0], w=obs[1], stack=obs[2])[5])
         else:
             r = np.random.default_rng(seed)
             batches.append(ReplayElement(state=r.normal(size=(B, 8)).astype(np.float32), action=r.integers(0, A, B).astype(np.int64),
@@ -244,6 +244,26 @@ def test_analysis_tfdqn_with_batchnorm_matches_the_oracle():
     for m, l in ora.agent.batch_stats.items():  # the evaluation forward's collection (analysistfdqn.py:85-95)
         for n, t in l.items():
             assert np.abs(got[m][n] - t.numpy()).max() < 2e-5 * max(1.0, float(t.abs().max())), (m, n)
+
+
+def test_batchnorm_impala_three_gradients_match_the_oracle():
+    """The impala torso with BatchNorm through the same three passes (max-pool winners and ReLU masks of small images: the bound of
+    tests/test_gpu_batchnorm.py's impala case -- 5e-2 of a leaf's largest entry, 15 % of the whole vector)."""
+    K, A, B = 2, 3, 9
+    hip, ora, (train, _ev) = _bn_pair("impala", K, A, B)
+    eng = hip._engine
+    g = hip.three_gradients(hip.params, hip.target_params, train)
+    o = ora.three_gradients(ora.params, ora.target_params, train)
+    for name, gg, oo in zip(("is", "tf", "tb"), g, o):
+        got = eng.internal_to_flax_grads(gg)
+        num = den = 0.0
+        for mod in oo:
+            for leaf in oo[mod]:
+                a, b = np.asarray(got[mod][leaf], np.float64), oo[mod][leaf].numpy().astype(np.float64)
+                assert np.abs(a - b).max() <= 5e-2 * max(np.abs(b).max(), 1e-6), (name, mod, leaf, np.abs(a - b).max(), np.abs(b).max())
+                num, den = num + float(((a - b) ** 2).sum()), den + float((b ** 2).sum())
+        assert num <= 0.15 ** 2 * den, (name, (num / den) ** 0.5)
+    assert not torch.allclose(g[2], g[1], rtol=1e-2, atol=1e-6)
 
 
 @pytest.mark.parametrize("algo", ["analysisdqn", "analysistfdqn"])
