@@ -80,13 +80,15 @@ def test_bench_refuses_a_gpu_count_that_differs_from_the_launched_world(tmp_path
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
 
 
-def test_bench_steps_per_graph_divides_timed_and_warmup_steps():
+def test_bench_steps_per_graph_divides_the_timed_steps():
     sys.path.insert(0, ROOT)
     import bench
 
-    assert bench.steps_per_graph(20, 5, 8) == 5      # the driver's --steps 20 --warmup 5: exactly 20 timed, 5 warm-up
-    assert bench.steps_per_graph(4000, 4000, 8) == 8
-    assert bench.steps_per_graph(7, 0, 8) == 7 and bench.steps_per_graph(20, 3, 8) == 1
+    # the timed region is exactly --steps: whole replays; the untimed phase (warm-up + declared settle steps) is rounded UP to replays
+    assert bench.steps_per_graph(20, 32) == 5        # the driver's --steps 20 --warmup 5: four replays of 5 timed steps
+    assert bench.steps_per_graph(20, 4) == 4
+    assert bench.steps_per_graph(4000, 32) == 32
+    assert bench.steps_per_graph(7, 8) == 1 and bench.steps_per_graph(24, 8) == 6 and bench.steps_per_graph(3, 8) == 1
 
 
 def test_launcher_refuses_incomplete_arguments_before_starting_anything():
