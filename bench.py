@@ -19,9 +19,10 @@ embarrassingly, no data-path collective; RCCL carries only the ti
 the environment; started as plain `python bench.py --gpus N` the parent spawns exactly that torchrun command as a child
 BEFORE touching any GPU and relays its output.  value = N * K / max-over-ranks(time).  ONE JSON line on rank 0.
 
-The timed region is EXACTLY --steps steps behind EXACTLY --warmup warm-up steps (the steps captured per hipGraph are
-chosen to divide both); an untimed settle phase in front of them (reported as `settle_steps`) takes a fresh process
-to its steady state, and a separate pass brackets single graph replays with HIP events for median / p10 / p90.
+The timed region is EXACTLY --steps steps (whole hipGraph replays: the steps captured per graph divide --steps and leave
+at least four replays in it) behind an untimed phase of whole replays -- at least --warmup steps plus the settle steps
+reported as `settle_steps`, which take a fresh process to its steady state; a separate pass brackets single graph
+replays with HIP events for median / p10 / p90.
 """
 import argparse
 import json
