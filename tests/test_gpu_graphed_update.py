@@ -115,6 +115,42 @@ def test_agent_update_online_params_graphed_equals_eager(prioritized):
         assert rb_g._sampling_distribution._sum_tree.max_recorded_priority >= 1.0
 
 
+@pytest.mark.parametrize("arch, batch_norm", [("cnn", True), ("impala", False), ("fc", True)])
+def test_captured_step_equals_eager_on_the_other_learn_paths(arch, batch_norm):
+    """The captured one-step graph (cnn torsos on the device replay: isdqn.py _graphed_update) replays WITHOUT rebuilding the weight
+    mirror whenever the engine's bookkeeping says the previous call left it current (slimdqn/_graph.py), so the BatchNorm learn path's
+    optimizer launches have to leave the mirror equal to the parameters they wrote.  Two agents, one with use_graph=False, same stream:
+    bit-identical after every update.  (impala / fc agents take the eager branch on both sides: the test pins that they still agree.)"""
+    from slimdqn.networks.isdqn import iSDQN
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+
+    K, A, B, C = 2, 4, 8, 40
+    obs, feats = ((8,), [24, 40]) if arch == "fc" else ((36, 36, 2), [8, 16, 8, 24])
+
+    def make(use_graph):
+        agent = iSDQN(0, obs, A, K, feats, True, batch_norm, arch, 2e-4, 0.99, 1, 1, 5, adam_eps=1.5e-4, batch_size=B, use_graph=use_graph)
+        rb = ReplayBuffer(UniformSamplingDistribution(5), B, C, stack_size=(1 if arch == "fc" else obs[2]), update_horizon=1, gamma=0.99)
+        return agent, rb
+
+    (eager, rb_e), (graphed, rb_g) = make(False), make(True)
+    assert torch.equal(eager._engine.params, graphed._engine.params)
+    rng = np.random.default_rng(0)
+    for step in range(1, 41):
+        o = rng.normal(size=obs).astype(np.float32) if arch == "fc" else rng.integers(0, 256, obs[:2], dtype=np.uint8)
+        a, r, term = int(rng.integers(0, A)), float(rng.choice([-1.0, 0.0, 1.0])), bool(rng.random() < 0.08)
+        for rb in (rb_e, rb_g):
+            rb.add(TransitionElement(o, a, r, term, term))
+        if step > 14:
+            for agent, rb in ((eager, rb_e), (graphed, rb_g)):
+                agent.update_online_params(step, rb)
+                agent.update_target_params(step)  # (every 5th step: the head shift invalidates the mirror)
+            for name in ("params", "adam_m", "adam_v", "adam_count", "losses_accum"):
+                x, y = getattr(eager._engine, name), getattr(graphed._engine, name)
+                assert torch.equal(x, y), f"step {step}: {name} differs between the eager and the captured step"
+    assert eager._graphed is None and (graphed._graphed is not None) == (arch == "cnn")
+
+
 def test_priorities_ready_event_orders_a_second_stream():
     """isdqn_batch.priorities_ready (include/isdqn_hip.h): the learn call records the caller's event once q_values / targets /
     priorities are final.  A second stream that only waits for that event must read the same priorities as a full
