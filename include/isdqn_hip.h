@@ -226,7 +226,7 @@ typedef struct isdqn_batch {
  * rebuilds it from `params` first -- `params` is caller-owned memory -- unless the caller passes this flag, promising that
  * the previous call on this workspace was isdqn_net_learn_on_batch with the same `params` and that nothing has written
  * `params` since (learn_on_batch leaves the mirror current: Adam writes both forms).  The captured multi-step graphs of
- * slimdqn/_graph.py use it for steps 2..S of a replay. */
+ * slimdqn/_graph.py use it for every step of a replay (isdqn_net_refresh_mirror in front of a replay when needed). */
 #define ISDQN_BATCH_MIRROR_CURRENT 1
 
 /* DQNNet.apply on `n_rows` observations (dqn.py:47-103) -> q [n_rows][n_heads*n_actions].
@@ -266,6 +266,11 @@ int isdqn_net_learn_on_batch_target(const isdqn_net_config* cfg, float* params, 
 int isdqn_net_loss_on_batch_target(const isdqn_net_config* cfg, const float* params, const float* target_params,
                                    const isdqn_batch* batch, float* losses, float* q_values, float* targets,
                                    void* workspace, void* stream);
+
+/* Rebuild the workspace's weight mirror from `params` now (what every entry point does at its head unless the caller passes
+ * ISDQN_BATCH_MIRROR_CURRENT).  For callers that replay a captured graph whose steps all trust the mirror: one eager launch in front
+ * of the replay when something wrote the parameters in between (slimdqn/_graph.py), instead of a second capture. */
+int isdqn_net_refresh_mirror(const isdqn_net_config* cfg, const float* params, void* workspace, void* stream);
 
 /* BatchNorm networks: params["batch_stats"] <- the batch_stats collection returned by the LAST training-mode forward that ran
  * in `workspace` (learn / loss / grad_on_batch; flax: apply(..., mutable=["batch_stats"])), i.e. running = 0.99 * running +

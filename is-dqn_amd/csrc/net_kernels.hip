@@ -2473,6 +2473,14 @@ extern "C" int isdqn_net_grad_on_batch(const isdqn_net_config* cfg, const float*
                          workspace, stream, true, grad_out, target_params, n_pairs > 0 ? &sel : nullptr, false);
 }
 
+extern "C" int isdqn_net_refresh_mirror(const isdqn_net_config* cfg, const float* params, void* workspace, void* stream) {
+    int rc;
+    const Plan* Pp = cached_plan(cfg, &rc);
+    if (!Pp) return rc;
+    ISDQN_REQUIRE(params != nullptr && workspace != nullptr, ISDQN_ERR_ARG, "null pointer");
+    return refresh_mirror(*Pp, params, (float*)workspace, (hipStream_t)stream);
+}
+
 extern "C" int isdqn_net_bn_commit_running(const isdqn_net_config* cfg, float* params, const void* workspace, void* stream) {
     int rc;
     const Plan* Pp = cached_plan(cfg, &rc);

@@ -424,6 +424,14 @@ class QNetEngine:
         return (params is None and getattr(self, "_mirror_version", None) == self.params._version
                 and self.params.data_ptr() == getattr(self, "_mirror_ptr", None))
 
+    def refresh_mirror(self) -> None:
+        """Rebuild the weight mirror from the engine's parameters now (one launch on the current stream) unless it is current."""
+        if self._mirror_is_current(None):
+            return
+        _hip.check(self.lib.isdqn_net_refresh_mirror(ctypes.byref(self.cfg), _hip.ptr(self.params), _hip.ptr(self.workspace),
+                                                     _hip.stream_ptr(self.device)), "isdqn_net_refresh_mirror")
+        self._mirror_made_current()
+
     def invalidate_mirror(self) -> None:
         """Force the next call to rebuild the weight mirror from ``params`` (for writers that bypass torch's version counter)."""
         self._mirror_version = None

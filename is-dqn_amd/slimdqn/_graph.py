@@ -45,24 +45,19 @@ class GraphedUpdate:
         self.terminal = torch.zeros(n_b, B, dtype=torch.uint8, device=dev)
         self._frames_ptr = rb._frames.data_ptr()
         self._make_batches()
-        # two captures of the same steps: `graph` rebuilds the weight mirror at its head (anything may have written the parameters
-        # since the last call), `graph_trusted` skips that 8 us launch and is replayed when the engine's bookkeeping says the
-        # mirror still matches the parameters (consecutive replays, acting in between: _engine.py _mirror_is_current)
+        # Every captured step takes the weight mirror as it is; run() rebuilds it in front of the replay (one eager 8 us launch) only
+        # when the engine's bookkeeping says something wrote the parameters since the last call that left it current (consecutive
+        # replays and acting in between do not: _engine.py _mirror_is_current).  (A second capture that rebuilds at its head was the
+        # first form of this; two graph executables over three streams crashed hipGraphLaunch -- hip::Graph::UpdateStreams -- in some
+        # test orders.)
         self.graph = None
-        self.graph_trusted = None
         self._capture()
-        self._capture(trusted=True)
 
     def _make_batches(self) -> None:
         rb, eng = self.rb, self.eng
-        # steps 2..S of a replay follow a learn step of the same graph directly: the weight mirror is current (the first
-        # step of a replay rebuilds it: anything may have written the parameters between two replays)
+        # every step of a replay finds the weight mirror current: steps 2..S follow a learn step of the same graph, step 1 follows
+        # run()'s check
         ev = lambda i: self._prio_ready[i] if self.prioritized else None
-        self.batches = [
-            eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids[i], action=self.action[i],
-                           reward=self.reward[i], terminal=self.terminal[i], priorities_ready=ev(i))
-            for i in range(self.frame_ids.shape[0])
-        ]
         self.chained = [
             eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids[i], action=self.action[i],
                            reward=self.reward[i], terminal=self.terminal[i], mirror_current=True, priorities_ready=ev(i))
@@ -81,10 +76,9 @@ class GraphedUpdate:
             "isdqn_replay_gather_rows",
         )
 
-    def _steps(self, trusted: bool = False) -> None:
-        """The S steps of one replay, enqueued on the current stream (``trusted``: the first step too takes the weight mirror as is)."""
+    def _steps(self) -> None:
+        """The S steps of one replay, enqueued on the current stream (the weight mirror must be current)."""
         rb, eng = self.rb, self.eng
-        first = self.chained if trusted else self.batches
         if self.prioritized:
             tree = rb._sampling_distribution._sum_tree
             main, sampling = torch.cuda.current_stream(eng.device), self._sampling_stream
@@ -92,7 +86,7 @@ class GraphedUpdate:
             self._gather(self.indices[0], self.B, 0)
             for s in range(self.S):
                 slot = s & 1
-                eng.learn_on_batch(first[slot] if s == 0 else self.chained[slot])
+                eng.learn_on_batch(self.chained[slot])
                 # under the rest of this step (backward, Adam): priorities of step s into the tree, then the draw and the row
                 # gather of step s+1 -- the order the reference's loop has (update, then sample)
                 sampling.wait_event(self._prio_ready[slot])
@@ -106,9 +100,9 @@ class GraphedUpdate:
         else:
             self._gather(self.block, self.S * self.B, 0)  # rows of all S steps: the [S][B] buffers are contiguous
             for s in range(self.S):
-                eng.learn_on_batch(first[s] if s == 0 else self.chained[s])
+                eng.learn_on_batch(self.chained[s])
 
-    def _capture(self, trusted: bool = False) -> None:
+    def _capture(self) -> None:
         # warm-up on a side stream (lazy one-time setup inside the library must not happen during capture)
         side = torch.cuda.Stream(self.eng.device)
         side.wait_stream(torch.cuda.current_stream(self.eng.device))
@@ -118,12 +112,13 @@ class GraphedUpdate:
         tree = self.rb._sampling_distribution._sum_tree if self.prioritized else None
         tree_state = [t.clone() for t in (tree._nodes_dev, tree._max_dev, tree._status)] if tree is not None else None
         with torch.cuda.stream(side):
-            self._steps()  # (the warm-up always rebuilds the mirror: the captured variant below may rely on it)
+            self.eng.refresh_mirror()
+            self._steps()
         torch.cuda.current_stream(self.eng.device).wait_stream(side)
         torch.cuda.synchronize(self.eng.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._steps(trusted)
+            self._steps()
         # the warm-up steps must not count: restore the training state
         for dst, src in zip((self.eng.params, self.eng.adam_m, self.eng.adam_v, self.eng.adam_count, self.eng.losses_accum), state):
             dst.copy_(src)
@@ -132,10 +127,7 @@ class GraphedUpdate:
                 dst.copy_(src)
         # the restored parameters are not what the warm-up's optimizer left in the mirror
         self.eng.invalidate_mirror()
-        if trusted:
-            self.graph_trusted = g
-        else:
-            self.graph = g
+        self.graph = g
 
     def run(self) -> None:
         """S steps: draw S index rows on the host stream of the sampler, stage them, replay the graph."""
@@ -145,9 +137,9 @@ class GraphedUpdate:
             self._frames_ptr = rb._frames.data_ptr()
             self._make_batches()
             self._capture()
-            self._capture(trusted=True)
         sampler = rb._sampling_distribution
         rows = sampler.draw_rows_device(self.S, self.B)
         self.block.copy_(rows, non_blocking=True)
-        (self.graph_trusted if self.eng._mirror_is_current(None) else self.graph).replay()
+        self.eng.refresh_mirror()  # (no launch when the mirror is current)
+        self.graph.replay()
         self.eng._mirror_made_current()  # the last step's optimizer wrote both forms of the weights

@@ -142,6 +142,7 @@ _SIGNATURES = {
         c_int32,
         [POINTER(NetConfig), c_void_p, c_void_p, POINTER(Batch), c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "isdqn_net_refresh_mirror": (c_int32, [POINTER(NetConfig), c_void_p, c_void_p, c_void_p]),
     "isdqn_net_bn_commit_running": (c_int32, [POINTER(NetConfig), c_void_p, c_void_p, c_void_p]),
     "isdqn_net_shift_params": (c_int32, [POINTER(NetConfig), c_void_p, c_void_p]),
     "isdqn_net_best_action": (

@@ -69,7 +69,7 @@ class iSDQN(EngineAgent):
         not the device replay of this GPU (reference-layout buffers take the eager path)."""
         if not self.use_graph or not hasattr(replay_buffer, "_d_elem_frames") or getattr(replay_buffer, "_lib", None) is None:
             return None
-        if self.architecture_type != "cnn" or replay_buffer.add_count == 0:
+        if self.architecture_type == "fc" or replay_buffer.add_count == 0:  # (fc batches are gathered by torch ops: eager)
             return None
         eng = self._engine_for(replay_buffer._batch_size)
         prioritized = hasattr(replay_buffer._sampling_distribution, "_tree")

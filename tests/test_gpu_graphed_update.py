@@ -39,9 +39,9 @@ def test_graph_replay_equals_eager_steps(workload):
 
 
 def test_trusted_graph_only_while_the_mirror_is_current():
-    """GraphedUpdate holds two captures: one that rebuilds the weight mirror at its head and one that takes it as is, replayed
-    only while the engine's bookkeeping (_engine.py: _mirror_is_current) says nothing wrote the parameters since the last replay.
-    A torch-side write and a head shift between replays must both be seen by the next replay."""
+    """Every captured step takes the weight mirror as it is; GraphedUpdate.run() rebuilds it in front of the replay only when the
+    engine's bookkeeping (_engine.py: _mirror_is_current) says something wrote the parameters since the last replay.  A torch-side
+    write and a head shift between replays must both be seen by the next replay."""
     S = 3
     eager, graphed = _replica("c2"), _replica("c2")
     graphed.enable_graph(S)
@@ -115,12 +115,12 @@ def test_agent_update_online_params_graphed_equals_eager(prioritized):
         assert rb_g._sampling_distribution._sum_tree.max_recorded_priority >= 1.0
 
 
-@pytest.mark.parametrize("arch, batch_norm", [("cnn", True), ("impala", False), ("fc", True)])
+@pytest.mark.parametrize("arch, batch_norm", [("cnn", True), ("impala", False), ("impala", True), ("fc", True)])
 def test_captured_step_equals_eager_on_the_other_learn_paths(arch, batch_norm):
-    """The captured one-step graph (cnn torsos on the device replay: isdqn.py _graphed_update) replays WITHOUT rebuilding the weight
-    mirror whenever the engine's bookkeeping says the previous call left it current (slimdqn/_graph.py), so the BatchNorm learn path's
-    optimizer launches have to leave the mirror equal to the parameters they wrote.  Two agents, one with use_graph=False, same stream:
-    bit-identical after every update.  (impala / fc agents take the eager branch on both sides: the test pins that they still agree.)"""
+    """The captured one-step graph (image torsos on the device replay: isdqn.py _graphed_update) replays WITHOUT rebuilding the weight
+    mirror whenever the engine's bookkeeping says the previous call left it current (slimdqn/_graph.py), so the optimizer launches of
+    the BatchNorm path and of the impala torso have to leave the mirror equal to the parameters they wrote.  Two agents, one with
+    use_graph=False, same stream: bit-identical after every update.  (fc agents take the eager branch on both sides.)"""
     from slimdqn.networks.isdqn import iSDQN
     from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
     from slimdqn.sample_collection.samplers import UniformSamplingDistribution
@@ -148,7 +148,7 @@ def test_captured_step_equals_eager_on_the_other_learn_paths(arch, batch_norm):
             for name in ("params", "adam_m", "adam_v", "adam_count", "losses_accum"):
                 x, y = getattr(eager._engine, name), getattr(graphed._engine, name)
                 assert torch.equal(x, y), f"step {step}: {name} differs between the eager and the captured step"
-    assert eager._graphed is None and (graphed._graphed is not None) == (arch == "cnn")
+    assert eager._graphed is None and (graphed._graphed is not None) == (arch != "fc")
 
 
 def test_priorities_ready_event_orders_a_second_stream():
