@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--K", type=int, default=0, help="override the number of Bellman iterations of the workload (the reference's "
                     "timing sweep launch_job/atari/launch_time.sh:13-27 runs K in 1, 4, 9, 49)")
+    ap.add_argument("--B", type=int, default=0, help="override the batch size of the workload (measurements only: the metric is quoted on the workload's own)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--capacity", type=int, default=1_000_000)
     ap.add_argument("--graph", type=int, default=32, help="most steps captured per hipGraph (0 = eager launches)")
@@ -305,6 +306,9 @@ def main():
     if args.K > 0:
         WORKLOADS[args.workload] = dict(WORKLOADS[args.workload], K=args.K, desc=WORKLOADS[args.workload]["desc"].replace(
             f"K={WORKLOADS[args.workload]['K']}", f"K={args.K}"))
+    if args.B > 0:
+        WORKLOADS[args.workload] = dict(WORKLOADS[args.workload], B=args.B, desc=WORKLOADS[args.workload]["desc"].replace(
+            f"B={WORKLOADS[args.workload]['B']}", f"B={args.B}"))
     w = WORKLOADS[args.workload]
 
     R = max(1, args.replicas_per_gpu)
