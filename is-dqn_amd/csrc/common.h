@@ -113,3 +113,11 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 }  // namespace isdqn
+
+// -DISDQN_EMPTY (measurement only, results are wrong by construction): every kernel of the learn step returns at once -- what is left
+// of the step is its launches, its graph edges and its kernel boundaries (scripts/r3/empty_step.sh)
+#if defined(ISDQN_EMPTY)
+#define ISDQN_EMPTY_KERNEL_RETURN return;
+#else
+#define ISDQN_EMPTY_KERNEL_RETURN
+#endif

@@ -223,6 +223,7 @@ __device__ __forceinline__ void fill_frames_u8(__bf16* img, const FrameSrc& fs, 
 // pixels between eight waves -- the LDS reads per MFMA stay the same.
 template <int MT, int PASSES, bool U8, int KG = 1>
 __global__ __launch_bounds__(GEMM_THREADS * KG, (U8 && MT == 2 && PASSES == 2) ? 4 : 1) void conv_fwd_img_kernel(const ConvImgParams p) {
+    ISDQN_EMPTY_KERNEL_RETURN
     using T = ConvImgTraits<MT, PASSES, U8>;
     using GA = typename T::GA;
     constexpr int NT = 2;
@@ -706,6 +707,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* a0, const __bf16* a1) {
 // workgroup and runs 4 K steps on each: with one wave per SIMD the two fills are most of its time.
 template <int MT, int NTW, int PASSES, bool U8, int WV = 4>
 __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgradImgParams p) {
+    ISDQN_EMPTY_KERNEL_RETURN
     constexpr int NTHR = 64 * WV;
     constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
     constexpr int B_PLANES = (PASSES >= 3) ? 2 : 1;
@@ -859,6 +861,7 @@ struct ConvDgradImgParams {
 // workgroups per CU, its own or a weight-gradient one, are worth more than the last two registers)
 template <int MT, int PASSES>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const ConvDgradImgParams p) {
+    ISDQN_EMPTY_KERNEL_RETURN
     constexpr int NT = 2;
     constexpr int BM = MT * 16;
     constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
@@ -1250,6 +1253,7 @@ struct ReduceJobs {
     int n;
 };
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceJobs jobs) {
+    ISDQN_EMPTY_KERNEL_RETURN
     __shared__ float s_red[32][8];
     int job = 0;
 #pragma unroll

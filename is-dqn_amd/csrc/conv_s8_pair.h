@@ -21,6 +21,7 @@ constexpr int S8P_BATCH = 6;  // chunks per thread: the whole LDS image (R * Wp 
 
 template <int NPOS>
 __global__ __launch_bounds__(GEMM_THREADS * 2, 1) void conv_fwd_s8_pair_kernel(const ConvImgParams p) {
+    ISDQN_EMPTY_KERNEL_RETURN
     constexpr int MT = 4, PASSES = 3, KG = 2, NT = 2, MTW = MT, NTHR = GEMM_THREADS, NTHR_ALL = GEMM_THREADS * KG;
     using T = ConvImgTraits<MT, PASSES, false>;
     using GA = typename T::GA;

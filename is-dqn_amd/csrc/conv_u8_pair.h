@@ -21,6 +21,7 @@ constexpr int U8P_PB = 2;  // positions per thread: one batch covers the whole t
 
 template <int PASSES, int NSTEPS>
 __global__ __launch_bounds__(GEMM_THREADS, 4) void conv_fwd_u8_pair_kernel(const ConvImgParams p) {
+    ISDQN_EMPTY_KERNEL_RETURN
     constexpr int MT = 2, NT = 2, MTW = MT, NTHR = GEMM_THREADS, STACK_MAX = 4;
     using T = ConvImgTraits<MT, PASSES, true>;
     using GA = typename T::GA;

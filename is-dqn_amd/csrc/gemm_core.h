@@ -259,6 +259,7 @@ struct GemmTraits {
 
 template <class P>
 __global__ __launch_bounds__(GEMM_THREADS * KGroupsOf<P>::value) void gemm_kernel(const P p) {
+    ISDQN_EMPTY_KERNEL_RETURN
     using T = GemmTraits<P>;
     constexpr int KG = T::KG;
     using GA = typename T::GA;

@@ -476,6 +476,7 @@ static inline int head_chain_lds_bytes(int Fp, int Op, int K, int passes, int S)
 
 template <int PASSES, int COLS, int SMAX>
 __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(const HeadChainParams p) {
+    ISDQN_EMPTY_KERNEL_RETURN
     extern __shared__ __attribute__((aligned(16))) char hc_smem[];
     const int PA = head_chain_pitch(p.Fp);
     constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
@@ -936,6 +937,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
                                                             float* __restrict__ loss_accum, float* __restrict__ dbh,
                                                             int* adam_count, float b1, float b2,
                                                             float* __restrict__ adam_consts) {
+    ISDQN_EMPTY_KERNEL_RETURN
     const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
     // One workgroup per 16 outputs (blocks [0, ceil(K/16)): losses, the rest: head-bias columns).  16 lanes share one
     // output: strided partial sums (eight loads in flight, added in index order), then a fixed shuffle tree.
@@ -993,6 +995,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* _
                                                    float* __restrict__ v, const float* __restrict__ consts, float lr,
                                                    float b1, float b2, float eps, float* __restrict__ grad_out,
                                                    float* __restrict__ mirror, int update) {
+    ISDQN_EMPTY_KERNEL_RETURN
     // A workgroup covers 16 float4 positions; 16 "slab lanes" per position split the slab reduction (up to a
     // few hundred split-K / per-image-group slabs for the conv kernels) and combine through LDS in a fixed
     // order, so the reduction is deterministic and never a long serial chain of dependent loads.
