@@ -16,10 +16,12 @@ from slimdqn import _hip
 
 
 class GraphedUpdate:
-    def __init__(self, rb, eng, prioritized: bool, steps_per_graph: int = 8, writeback: bool | None = None):
+    def __init__(self, rb, eng, prioritized: bool, steps_per_graph: int = 8, writeback: bool | None = None, learn=None):
         """``prioritized``: the sampler is a sum tree (the query is part of the graph); ``writeback``: sqrt(mean_k td) of
-        every step goes back into the tree (default: whenever prioritized)."""
+        every step goes back into the tree (default: whenever prioritized); ``learn``: the learn call of one step on a C batch
+        (default ``eng.learn_on_batch``; DQN passes its target-parameter form, dqn.py:59-72)."""
         self.rb, self.eng, self.prioritized, self.S = rb, eng, prioritized, steps_per_graph
+        self._learn = eng.learn_on_batch if learn is None else learn
         self.writeback = prioritized if writeback is None else (writeback and prioritized)
         dev, B, s2 = eng.device, eng.batch_size, 2 * rb._stack_size
         self.B = B
@@ -86,7 +88,7 @@ class GraphedUpdate:
             self._gather(self.indices[0], self.B, 0)
             for s in range(self.S):
                 slot = s & 1
-                eng.learn_on_batch(self.chained[slot])
+                self._learn(self.chained[slot])
                 # under the rest of this step (backward, Adam): priorities of step s into the tree, then the draw and the row
                 # gather of step s+1 -- the order the reference's loop has (update, then sample)
                 sampling.wait_event(self._prio_ready[slot])
@@ -100,7 +102,7 @@ class GraphedUpdate:
         else:
             self._gather(self.block, self.S * self.B, 0)  # rows of all S steps: the [S][B] buffers are contiguous
             for s in range(self.S):
-                eng.learn_on_batch(self.chained[s])
+                self._learn(self.chained[s])
 
     def _capture(self) -> None:
         # warm-up on a side stream (lazy one-time setup inside the library must not happen during capture)

@@ -108,6 +108,25 @@ class EngineAgent:
     def _engine_changed(self, old) -> None:
         """Hook: a new engine replaced ``old`` (subclasses re-home extra device state)."""
 
+    def _graphed_update(self, replay_buffer, learn=None, key=None):
+        """The captured sample -> learn -> [write-back] step for this (replay, engine) pair, or None when the replay is not the device
+        replay of this GPU (reference-layout buffers take the eager path).  ``learn`` / ``key``: another learn call than the engine's
+        learn_on_batch and what it is bound to (DQN: the target parameters' buffer) -- a new key captures again."""
+        if not getattr(self, "use_graph", True) or not hasattr(replay_buffer, "_d_elem_frames") or getattr(replay_buffer, "_lib", None) is None:
+            return None
+        if self.architecture_type == "fc" or replay_buffer.add_count == 0:  # (fc batches are gathered by torch ops: eager)
+            return None
+        eng = self._engine_for(replay_buffer._batch_size)
+        prioritized = hasattr(replay_buffer._sampling_distribution, "_tree")
+        writeback = bool(getattr(self, "priority_writeback", False))
+        g = self._graphed
+        if g is None or g.rb is not replay_buffer or g.eng is not eng or g.writeback != (writeback and prioritized) or getattr(g, "key", None) != key:
+            from slimdqn._graph import GraphedUpdate
+
+            g = self._graphed = GraphedUpdate(replay_buffer, eng, prioritized, steps_per_graph=1, writeback=writeback, learn=learn)
+            g.key = key
+        return g
+
     def _engine_for(self, batch_size: int) -> QNetEngine:
         if self._engine.batch_size != batch_size:
             self._make_engine(batch_size)

@@ -32,7 +32,9 @@ class DQN(EngineAgent):
         batch_size: int = 32,
         precision: str = "bf16x3",
         device: str | None = None,
+        use_graph: bool = True,
     ):
+        self.use_graph = bool(use_graph)  # update_online_params on a device replay replays a captured step (networks/_agent.py)
         self.network = DQNNet([int(f) for f in features], architecture_type, n_actions, layer_norm, False)
         self.data_to_update = data_to_update
         self.target_update_frequency = target_update_frequency
@@ -49,6 +51,12 @@ class DQN(EngineAgent):
     # ------------------------------------------------------------------ dqn.py:40-57
     def update_online_params(self, step: int, replay_buffer):
         if step % self.data_to_update == 0:
+            target = self._target_tensor(self.target_params)
+            eng = self._engine_for(replay_buffer._batch_size) if hasattr(replay_buffer, "_batch_size") else self._engine
+            g = self._graphed_update(replay_buffer, learn=lambda cb: eng.learn_on_batch_target(cb, target), key=target.data_ptr())
+            if g is not None:  # (captured against THIS target copy: update_target_params makes a new one, which captures again)
+                g.run()
+                return
             batch_samples = replay_buffer.sample()
             self.params, self.optimizer_state, _ = self.learn_on_batch(self.params, self.target_params, self.optimizer_state, batch_samples)
             # `cumulated_loss += loss` (dqn.py:47) happens on the device inside the step

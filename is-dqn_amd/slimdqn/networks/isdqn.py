@@ -64,22 +64,6 @@ class iSDQN(EngineAgent):
         self.cumulated_losses = np.zeros(self.n_bellman_iterations)
 
     # ------------------------------------------------------------------ isdqn.py:55-80
-    def _graphed_update(self, replay_buffer):
-        """The captured sample -> learn -> [write-back] step for this (replay, engine) pair, or None when the replay is
-        not the device replay of this GPU (reference-layout buffers take the eager path)."""
-        if not self.use_graph or not hasattr(replay_buffer, "_d_elem_frames") or getattr(replay_buffer, "_lib", None) is None:
-            return None
-        if self.architecture_type == "fc" or replay_buffer.add_count == 0:  # (fc batches are gathered by torch ops: eager)
-            return None
-        eng = self._engine_for(replay_buffer._batch_size)
-        prioritized = hasattr(replay_buffer._sampling_distribution, "_tree")
-        g = self._graphed
-        if g is None or g.rb is not replay_buffer or g.eng is not eng or g.writeback != (self.priority_writeback and prioritized):
-            from slimdqn._graph import GraphedUpdate
-
-            g = self._graphed = GraphedUpdate(replay_buffer, eng, prioritized, steps_per_graph=1, writeback=self.priority_writeback)
-        return g
-
     def learn_steps(self, n_steps: int, replay_buffer) -> None:
         """``n_steps`` consecutive gradient steps (sample -> learn -> [write-back] each) on an unchanged replay buffer: what
         n_steps calls of ``update_online_params`` at update steps do, as ONE graph replay when the replay is this GPU's

@@ -31,7 +31,9 @@ class TFDQN(EngineAgent):
         batch_size: int = 32,
         precision: str = "bf16x3",
         device: str | None = None,
+        use_graph: bool = True,
     ):
+        self.use_graph = bool(use_graph)  # update_online_params on a device replay replays a captured step (networks/_agent.py)
         self.network = DQNNet([int(f) for f in features], architecture_type, n_actions, layer_norm, batch_norm)
         self.data_to_update = data_to_update
         self.target_update_frequency = target_update_frequency
@@ -42,6 +44,10 @@ class TFDQN(EngineAgent):
     # ------------------------------------------------------------------ tfdqn.py:38-54
     def update_online_params(self, step: int, replay_buffer):
         if step % self.data_to_update == 0:
+            g = self._graphed_update(replay_buffer)
+            if g is not None:
+                g.run()  # same draws, same kernels, same bits as the eager branch below
+                return
             batch_samples = replay_buffer.sample()
             self.params, self.optimizer_state, _ = self.learn_on_batch(self.params, self.optimizer_state, batch_samples)
 

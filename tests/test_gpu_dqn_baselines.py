@@ -270,3 +270,49 @@ def test_fc_plans_of_the_baselines_match_the_oracle(kind, plan):
         for leaf in p[mod]:
             assert np.abs(got[mod][leaf] - p[mod][leaf].numpy()).max() < 3 * 2.001e-3, (mod, leaf)
     assert int(eng.adam_count.item()) == 3
+
+
+@pytest.mark.parametrize("kind, prioritized", [("tfdqn", False), ("tfdqn", True), ("dqn", False), ("dqn", True)])
+def test_captured_update_step_of_the_baselines_equals_the_eager_one(kind, prioritized):
+    """TFDQN / DQN.update_online_params on a device replay replays a captured one-step graph (networks/_agent.py _graphed_update; DQN's
+    is bound to its current target copy and captured again after every update_target_params, dqn.py:49-50).  Two agents, one with
+    use_graph=False, fed the same stream through a buffer that grows, fills up and evicts: parameters, Adam state and accumulated loss
+    bit-identical after every update, the target copies too."""
+    from slimdqn.networks.dqn import DQN
+    from slimdqn.networks.tfdqn import TFDQN
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import PrioritizedSamplingDistribution, UniformSamplingDistribution
+
+    A, B, C = 5, 8, 48
+
+    def make(use_graph):
+        if kind == "tfdqn":
+            agent = TFDQN(0, (84, 84, 4), A, [8, 12, 16, 24], True, False, "cnn", 2e-4, 0.99, 3, 2, 6, adam_eps=1.5e-4, batch_size=B, use_graph=use_graph)
+        else:
+            agent = DQN(0, (84, 84, 4), A, [8, 12, 16, 24], True, "cnn", 2e-4, 0.99, 3, 2, 6, adam_eps=1.5e-4, batch_size=B, use_graph=use_graph)
+        sampler = PrioritizedSamplingDistribution(5, C) if prioritized else UniformSamplingDistribution(5)
+        return agent, ReplayBuffer(sampler, B, C, update_horizon=3, gamma=0.99)
+
+    (eager, rb_e), (graphed, rb_g) = make(False), make(True)
+    assert torch.equal(eager._engine.params, graphed._engine.params)
+    rng = np.random.default_rng(0)
+    n_updates = 0
+    for step in range(1, 71):
+        obs = rng.integers(0, 256, (84, 84), dtype=np.uint8)
+        a, r, term = int(rng.integers(0, A)), float(rng.choice([-1.0, 0.0, 1.0])), bool(rng.random() < 0.08)
+        for rb in (rb_e, rb_g):
+            kw = dict(priority=rb._sampling_distribution.MAX_PRIORITY) if prioritized else {}
+            rb.add(TransitionElement(obs, a, r, term, term), **kw)
+        if step > 14:
+            for agent, rb in ((eager, rb_e), (graphed, rb_g)):
+                agent.update_online_params(step, rb)
+            le, lg = eager.update_target_params(step), graphed.update_target_params(step)
+            assert le[0] == lg[0] and (not le[0] or le[1] == lg[1])  # same cadence, same logged loss
+            if step % 2 == 0:
+                n_updates += 1
+                for name in ("params", "adam_m", "adam_v", "adam_count", "losses_accum"):
+                    x, y = getattr(eager._engine, name), getattr(graphed._engine, name)
+                    assert torch.equal(x, y), f"step {step}: {name} differs between the eager and the captured step"
+                if kind == "dqn":
+                    assert torch.equal(eager.target_params.tensor, graphed.target_params.tensor)
+    assert n_updates >= 25 and graphed._graphed is not None and eager._graphed is None
