@@ -45,6 +45,13 @@ class GraphedUpdate:
         self.action = torch.zeros(n_b, B, dtype=torch.int32, device=dev)
         self.reward = torch.zeros(n_b, B, dtype=torch.float32, device=dev)
         self.terminal = torch.zeros(n_b, B, dtype=torch.uint8, device=dev)
+        # vector observations (the fc torso, LunarLander): the replay stores the bytes of every float32 observation as one 1 x 4d "frame";
+        # the captured step materialises the B state / next-state rows of a batch into static buffers the engine reads as (B, d) float32
+        self.fc = eng.architecture_type == "fc"
+        if self.fc:
+            if not rb._obs_float or rb._stack_size != 1:
+                raise NotImplementedError("captured fc step: float32 vector observations with stack_size 1")
+            self.obs = torch.zeros(2, n_b * B, rb._w, dtype=torch.uint8, device=dev)  # [state | next_state][slot * B + b][4 d]
         self._frames_ptr = rb._frames.data_ptr()
         self._make_batches()
         # Every captured step takes the weight mirror as it is; run() rebuilds it in front of the replay (one eager 8 us launch) only
@@ -60,6 +67,15 @@ class GraphedUpdate:
         # every step of a replay finds the weight mirror current: steps 2..S follow a learn step of the same graph, step 1 follows
         # run()'s check
         ev = lambda i: self._prio_ready[i] if self.prioritized else None
+        if self.fc:
+            B = self.B
+            rows = lambda half, i: self.obs[half, i * B:(i + 1) * B].view(torch.float32)
+            self.chained = [
+                eng.make_batch(state=rows(0, i), next_state=rows(1, i), action=self.action[i], reward=self.reward[i], terminal=self.terminal[i],
+                               mirror_current=True, priorities_ready=ev(i))
+                for i in range(self.frame_ids.shape[0])
+            ]
+            return
         self.chained = [
             eng.make_batch(frames=rb._frames, frame_stride=rb._hw, frame_ids=self.frame_ids[i], action=self.action[i],
                            reward=self.reward[i], terminal=self.terminal[i], mirror_current=True, priorities_ready=ev(i))
@@ -78,6 +94,17 @@ class GraphedUpdate:
             "isdqn_replay_gather_rows",
         )
 
+    def _materialize(self, slot: int, n_rows: int) -> None:
+        """fc: the observation rows of ``n_rows`` gathered transitions, from batch slot ``slot`` on."""
+        rb, B = self.rb, self.B
+        _hip.check(
+            rb._lib.isdqn_replay_materialize(
+                _hip.ptr(rb._frames), rb._hw, rb._h, rb._w, rb._stack_size, _hip.ptr(self.frame_ids[slot]), n_rows,
+                _hip.ptr(self.obs[0, slot * B:]), _hip.ptr(self.obs[1, slot * B:]), _hip.stream_ptr(self.eng.device),
+            ),
+            "isdqn_replay_materialize",
+        )
+
     def _steps(self) -> None:
         """The S steps of one replay, enqueued on the current stream (the weight mirror must be current)."""
         rb, eng = self.rb, self.eng
@@ -88,6 +115,8 @@ class GraphedUpdate:
             self._gather(self.indices[0], self.B, 0)
             for s in range(self.S):
                 slot = s & 1
+                if self.fc:
+                    self._materialize(slot, self.B)
                 self._learn(self.chained[slot])
                 # under the rest of this step (backward, Adam): priorities of step s into the tree, then the draw and the row
                 # gather of step s+1 -- the order the reference's loop has (update, then sample)
@@ -101,6 +130,8 @@ class GraphedUpdate:
                 main.wait_stream(sampling)
         else:
             self._gather(self.block, self.S * self.B, 0)  # rows of all S steps: the [S][B] buffers are contiguous
+            if self.fc:
+                self._materialize(0, self.S * self.B)
             for s in range(self.S):
                 self._learn(self.chained[s])
 

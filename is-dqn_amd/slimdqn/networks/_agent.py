@@ -114,8 +114,10 @@ class EngineAgent:
         learn_on_batch and what it is bound to (DQN: the target parameters' buffer) -- a new key captures again."""
         if not getattr(self, "use_graph", True) or not hasattr(replay_buffer, "_d_elem_frames") or getattr(replay_buffer, "_lib", None) is None:
             return None
-        if self.architecture_type == "fc" or replay_buffer.add_count == 0:  # (fc batches are gathered by torch ops: eager)
+        if replay_buffer.add_count == 0:
             return None
+        if self.architecture_type == "fc" and not (replay_buffer._obs_float and replay_buffer._stack_size == 1):
+            return None  # (the captured fc step reads float32 vector observations with stack_size 1: _graph.py)
         eng = self._engine_for(replay_buffer._batch_size)
         prioritized = hasattr(replay_buffer._sampling_distribution, "_tree")
         writeback = bool(getattr(self, "priority_writeback", False))

@@ -115,12 +115,13 @@ def test_agent_update_online_params_graphed_equals_eager(prioritized):
         assert rb_g._sampling_distribution._sum_tree.max_recorded_priority >= 1.0
 
 
-@pytest.mark.parametrize("arch, batch_norm", [("cnn", True), ("impala", False), ("impala", True), ("fc", True)])
+@pytest.mark.parametrize("arch, batch_norm", [("cnn", True), ("impala", False), ("impala", True), ("fc", False), ("fc", True)])
 def test_captured_step_equals_eager_on_the_other_learn_paths(arch, batch_norm):
-    """The captured one-step graph (image torsos on the device replay: isdqn.py _graphed_update) replays WITHOUT rebuilding the weight
-    mirror whenever the engine's bookkeeping says the previous call left it current (slimdqn/_graph.py), so the optimizer launches of
-    the BatchNorm path and of the impala torso have to leave the mirror equal to the parameters they wrote.  Two agents, one with
-    use_graph=False, same stream: bit-identical after every update.  (fc agents take the eager branch on both sides.)"""
+    """The captured one-step graph (networks/_agent.py _graphed_update) replays WITHOUT rebuilding the weight mirror whenever the
+    engine's bookkeeping says the previous call left it current (slimdqn/_graph.py), so the optimizer launches of the BatchNorm path,
+    of the impala torso and of the all-dense plan have to leave the mirror equal to the parameters they wrote; the fc step also
+    materialises its float32 observation rows inside the graph.  Two agents, one with use_graph=False, same stream: bit-identical after
+    every update."""
     from slimdqn.networks.isdqn import iSDQN
     from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
     from slimdqn.sample_collection.samplers import UniformSamplingDistribution
@@ -148,7 +149,7 @@ def test_captured_step_equals_eager_on_the_other_learn_paths(arch, batch_norm):
             for name in ("params", "adam_m", "adam_v", "adam_count", "losses_accum"):
                 x, y = getattr(eager._engine, name), getattr(graphed._engine, name)
                 assert torch.equal(x, y), f"step {step}: {name} differs between the eager and the captured step"
-    assert eager._graphed is None and (graphed._graphed is not None) == (arch != "fc")
+    assert eager._graphed is None and graphed._graphed is not None
 
 
 def test_priorities_ready_event_orders_a_second_stream():
