@@ -35,6 +35,8 @@ sys.path.insert(0, os.path.join(ROOT, "is-dqn_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_GBS = 6290.0  # same guide ("~6.3 TB/s achievable"; SURVEY.md 8(d): 6.29 TB/s measured copy)
+MFMA_PEAK_FLOPS = 2.5e15  # dense bf16 MFMA peak
 
 WORKLOADS = {
     "c2": dict(n_actions=9, K=9, B=256, prioritized=False, n=1, desc="Asterix-shaped iS-DQN K=9 A=9 B=256 cnn32/64/64/512+LN, uniform device replay, n=1"),
@@ -59,6 +61,18 @@ def algorithmic_flops_per_step(B, K, A):
     mac = 16_003_072 + 512 * (1 + K) * A
     mac_conv0 = 441 * 256 * 32
     return 2 * mac * 2 * B + 2 * (2 * mac - mac_conv0) * B
+
+
+def mfma_floor_seconds(B, K, A, precision):
+    """The matrix-pipe floor of one step AT THE CHOSEN PRECISION: every contraction's algorithmic flops x the bf16 MFMA passes it is
+    computed in, at the dense peak.  bf16x3 = hi*hi + lo*hi + hi*lo (3 passes); the first convolution's uint8 pixels are exact in
+    bf16, so it takes 2 (forward, on 2B images) and its weight gradient 2 (no data gradient for the input layer); bf16 = 1 pass.
+    DESIGN.md section 4: at bf16x3 this floor (c2: 35 us) is already ABOVE the 28.5 us that "70 % of the HBM roofline" allows."""
+    mac = 16_003_072 + 512 * (1 + K) * A
+    mac_conv0 = 441 * 256 * 32
+    p, p0 = (3, 2) if precision == "bf16x3" else (1, 1)
+    flop_passes = 6 * mac_conv0 * B * p0 + 8 * (mac - mac_conv0) * B * p  # fwd on 2B + wgrad on B | fwd on 2B + dgrad + wgrad on B
+    return flop_passes / MFMA_PEAK_FLOPS
 
 
 def measured_traffic(workload, precision):
@@ -361,6 +375,11 @@ def main():
     rep.rb._sampling_distribution._sum_tree.check_status() if w["prioritized"] else None
 
     elapsed_max = max_over_ranks(elapsed, device)
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    if dist is not None:  # every rank's own ms_per_step: a straggler (a slow GPU, a busy host core) is visible in the line
+        t_all = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(t_all, torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=device))
+        per_rank_ms = [float(t.item()) for t in t_all]
 
     # distribution over single replays (own pass, outside the timed region: every replay bracketed by its own events)
     stats = None
@@ -384,6 +403,8 @@ def main():
         flops_step = algorithmic_flops_per_step(w["B"], w["K"], w["n_actions"])
         achieved = bytes_step / (dev_ms_avg * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(args.workload, args.precision)
+        floor_s = mfma_floor_seconds(w["B"], w["K"], w["n_actions"], args.precision)
+        hbm_s = bytes_step / (HBM_PEAK_GBS * 1e9)
         out = {
             "metric": f"gradient-steps/sec (batch={w['B']}, K={w['K']}, 84x84x4)",
             "value": aggregate_value(world * R, args.steps, elapsed_max),
@@ -393,6 +414,7 @@ def main():
             "warmup": args.warmup,
             "settle_steps": settle,
             "ms_per_step": elapsed_max / args.steps * 1e3,
+            "ms_per_step_per_rank": per_rank_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -406,7 +428,14 @@ def main():
                 "kernel": "replay-sample -> Bellman-update step (all launches of one step; HIP-event time per step)",
                 "algorithmic_bytes_per_step": bytes_step, "device_ms_per_step_avg": dev_ms_avg,
                 "host_issue_ms_per_step": t_issue / args.steps * 1e3,
-                "mfma_util_vs_2.5PF": flops_step / (dev_ms_avg * 1e-3) / 2.5e15,
+                "mfma_util_vs_2.5PF": flops_step / (dev_ms_avg * 1e-3) / MFMA_PEAK_FLOPS,
+                # the same achieved rate against the copy bandwidth this part really delivers (SURVEY 8d asks for both)
+                "frac_vs_measured_bw": achieved / HBM_MEASURED_GBS, "measured_bw_GBs": HBM_MEASURED_GBS,
+                # what the chosen arithmetic allows at best: the step cannot take less than its MFMA passes at the dense peak, so
+                # `frac` is capped at hbm_time / max(hbm_time, mfma_floor) whatever the kernels do
+                "mfma_floor_us_at_precision": floor_s * 1e6, "hbm_time_us_at_peak": hbm_s * 1e6,
+                "max_frac_at_mfma_floor": hbm_s / max(hbm_s, floor_s),
+                "frac_of_attainable": (achieved / HBM_PEAK_GBS) / (hbm_s / max(hbm_s, floor_s)),
             },
         }
         if stats is not None:

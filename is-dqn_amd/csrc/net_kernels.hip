@@ -14,7 +14,6 @@
 #include "conv_img.h"
 #include "conv_u8_pair.h"
 #include "conv_s8_pair.h"
-#include "conv_ws.h"
 #include "net_plan.h"
 #include "net_problems.h"
 
@@ -1288,53 +1287,9 @@ static int conv_fwd_img(const Layer& l, bool x3, const float* params, const floa
          : kg2 ? launch_conv_fwd_img<4, 1, false, 2>(ip, st) : launch_conv_fwd_img<4, 1, false>(ip, st);
 }
 
-// weights-stationary forward (conv_ws.h) for the layers whose whole weight matrix fits the LDS of a CU
-static int conv_fwd_ws(const Layer& l, bool x3, const float* params, const float* wmir, const float* act_in, int n_img, int z_img,
-                       float* act, float* z, hipStream_t st, bool* done) {
-    *done = false;
-    // Round-3 experiment, measured and NOT taken by the product build (profiles/round3/ws_*): at the
-    // headline size it runs level with the image-resident kernels (24.9 vs 25.7 / 22.1 us).  -DISDQN_WS builds take it.
-#if !defined(ISDQN_WS)
-    return ISDQN_OK;
-#endif
-    if (l.is_u8 || (l.cin_p != 32 && l.cin_p != 64) || l.K != l.taps * l.cin_p) return ISDQN_OK;
-    ConvWsParams wp;
-    wp.g = conv_geom(l);
-    const int passes = x3 ? 3 : 1;
-    const int lds = conv_ws_lds_bytes(wp.g, passes);
-    if (lds == 0 || lds > 158 * 1024) return ISDQN_OK;
-    wp.W = wmir + l.w_off;
-    wp.in = act_in;
-    wp.bias = params + l.b_off;
-    wp.gamma = l.has_ln ? params + l.g_off : nullptr;
-    wp.beta = l.has_ln ? params + l.be_off : nullptr;
-    wp.act = act; wp.z = z; wp.n_img = n_img; wp.z_img = z_img;
-    const int64_t in_bytes = (int64_t)n_img * l.in_elems_p * 4;
-    if (in_bytes >= (int64_t)1 << 31) return ISDQN_OK;  // (buffer offsets: the image-resident kernel takes larger batches)
-    wp.in_bytes = (unsigned)in_bytes;
-    wp.stamps = stamps_for(l.name);
-    wp.ablate = 0;
-#if defined(ISDQN_DEV)
-    if (const char* e = getenv("ISDQN_ABLATE")) wp.ablate = atoi(e);
-#endif
-    *done = true;
-    const int mt = l.cout_p <= 32 ? 2 : 4;
-#if defined(ISDQN_WS_NT2)
-    constexpr int WS_WAVES = 8, WS_NT = 2;
-#elif defined(ISDQN_WS_WAVES)
-    constexpr int WS_WAVES = ISDQN_WS_WAVES, WS_NT = 1;
-#else
-    constexpr int WS_WAVES = 16, WS_NT = 1;
-#endif
-    if (passes == 3) return mt == 2 ? launch_conv_fwd_ws<2, 3, WS_WAVES, WS_NT>(wp, lds, st) : launch_conv_fwd_ws<4, 3, WS_WAVES, WS_NT>(wp, lds, st);
-    return mt == 2 ? launch_conv_fwd_ws<2, 1, WS_WAVES, WS_NT>(wp, lds, st) : launch_conv_fwd_ws<4, 1, WS_WAVES, WS_NT>(wp, lds, st);
-}
-
 static int conv_fwd(const Layer& l, bool x3, const float* params, const float* wmir, const NetInput& in, const float* act_in, int n_img,
                     int z_img, float* act, float* z, hipStream_t st) {
     bool done = false;
-    int rc_ws = conv_fwd_ws(l, x3, params, wmir, act_in, n_img, z_img, act, z, st, &done);
-    if (rc_ws || done) return rc_ws;
     int rc = conv_fwd_img(l, x3, params, wmir, in, act_in, n_img, z_img, act, z, st, &done);
     if (rc || done) return rc;
     const bool small = l.cout_p <= 32;
@@ -1662,64 +1617,6 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
     else rc = mt == 2 ? launch_conv_dgrad_img<2, 1>(dp, st) : launch_conv_dgrad_img<4, 1>(dp, st);
     if (rc) return rc;
     add_reduce_job(*jobs, ws + below.part_off, n_img * dp.tiles_per_img, 3 * below.out_p, ws + below.red_off);
-    *done = true;
-    return ISDQN_OK;
-}
-
-// weights-stationary data gradient + LayerNorm backward of the layer below (conv_ws.h): 32-channel input layers whose weights
-// of all stride classes fit the LDS of a CU
-static int conv_dgrad_ws(const Layer& l, const Layer& below, bool x3, const float* params, const float* wmir, const float* dz, float* ws,
-                         int n_img, hipStream_t st, bool* done, ReduceJobs* jobs) {
-    *done = false;
-    // Round-3 experiment, NOT taken by the product build: 27.7 us alone / 42.7 us beside the weight-gradient
-    // stream against 25.1 / 40.5 us of conv_dgrad_img_kernel<2, 3>.  -DISDQN_WS builds take it.
-#if !defined(ISDQN_WS) || defined(ISDQN_NO_WS_DGRAD)
-    return ISDQN_OK;
-#endif
-    if (l.is_u8 || l.cin_p != 32 || (l.cout_p != 32 && l.cout_p != 64) || l.ksz % l.stride != 0 || l.stride > 2 || l.K != l.taps * l.cin_p)
-        return ISDQN_OK;
-    const int passes = x3 ? 3 : 1, PL = passes >= 2 ? 2 : 1;
-    const int lds = l.taps * (l.cout_p / 32) * PL * 32 * 64;
-    const int64_t dz_bytes = (int64_t)n_img * l.out_elems_p * 4;
-    constexpr int WAVES = 16;
-    if (lds > 150 * 1024 || dz_bytes >= (int64_t)1 << 31) return ISDQN_OK;
-    ConvDgradWsParams dp;
-    dp.g = conv_geom(l);
-    dp.W = wmir + l.w_off;
-    dp.dz = dz;
-    dp.z_in = ws + below.z_off;
-    dp.gamma = below.has_ln ? params + below.g_off : nullptr;
-    dp.beta = below.has_ln ? params + below.be_off : nullptr;
-    dp.c_in = below.out_f;
-    dp.dz_in = ws + below.dz_off;
-    dp.part = ws + below.part_off;
-    dp.n_img = n_img;
-    dp.T = l.ksz / l.stride;
-    dp.d_T = FastDiv((uint32_t)dp.T);
-    dp.n_classes = l.stride * l.stride;
-    int acc = 0;
-    for (int c = 0; c < dp.n_classes; ++c) {
-        const int cy = c / l.stride, cx = c % l.stride;
-        const int Ha = (l.hin - cy + l.stride - 1) / l.stride, Wb = (l.win - cx + l.stride - 1) / l.stride;
-        dp.cls_tile_start[c] = acc;
-        dp.cls_d_w[c] = FastDiv((uint32_t)Wb);
-        acc += ceil_div(Ha * Wb, 16);
-    }
-    dp.cls_tile_start[dp.n_classes] = acc;
-    dp.tiles_per_img = acc;
-    dp.d_tpi = FastDiv((uint32_t)acc);
-    dp.n_tiles = n_img * acc;
-    dp.dz_bytes = (unsigned)dz_bytes;
-    {
-        char tag[32];
-        snprintf(tag, sizeof(tag), "dgrad:%s", l.name);
-        dp.stamps = stamps_for(tag);
-    }
-    const int grid = std::min(256, ceil_div(dp.n_tiles, WAVES));
-    if (below.part_rows < grid) return ISDQN_OK;
-    int rc = passes == 3 ? launch_conv_dgrad_ws<3>(dp, lds, grid, st) : launch_conv_dgrad_ws<1>(dp, lds, grid, st);
-    if (rc) return rc;
-    add_reduce_job(*jobs, ws + below.part_off, grid, 3 * below.out_p, ws + below.red_off);
     *done = true;
     return ISDQN_OK;
 }
@@ -2217,9 +2114,7 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
         dz_fused = false;
         if (i > 0) {
             if (l.kind == 0) {
-                rc = conv_dgrad_ws(l, P.L[i - 1], x3, params, wmir, dz_cur, ws, B, st, &dz_fused, &red_jobs);
-                if (rc) return rc;
-                if (!dz_fused) rc = conv_dgrad_img(l, P.L[i - 1], x3, params, wmir, dz_cur, ws, B, st, &dz_fused, &red_jobs);
+                rc = conv_dgrad_img(l, P.L[i - 1], x3, params, wmir, dz_cur, ws, B, st, &dz_fused, &red_jobs);
                 if (rc) return rc;
             }
             if (l.kind == 1 && P.L[i - 1].kind != 1 && P.L[i - 1].cout_p == 64 && !l.in_unpadded_ld &&

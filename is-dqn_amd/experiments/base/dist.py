@@ -33,7 +33,12 @@ def init_from_env(backend: str = None, force: bool = False):
         return 1, 0
     if ws <= 1:
         ws, rank = 1, 0
-        os.environ.setdefault("MASTER_PORT", "29531")
+        if "MASTER_PORT" not in os.environ:  # a forced one-rank group: any free port (two such runs on one host must not collide)
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
     import torch
     import torch.distributed as dist
 

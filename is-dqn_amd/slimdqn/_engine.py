@@ -5,6 +5,7 @@ wrappers over the C-ABI entry points.  Pure plumbing: no arithmetic of the hot p
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from typing import Dict, Sequence
 
@@ -411,26 +412,32 @@ class QNetEngine:
         self._mirror_holds(params)
         return feats, list(torch.split(scores, sizes))
 
-    # ------------------------------------------------------------------ weight-mirror bookkeeping (acting path)
+    # ------------------------------------------------------------------ weight-mirror bookkeeping
     # The library keeps a pre-split mirror of the weights in the workspace and rebuilds it at the head of every call unless
-    # told that it is current.  learn_on_batch leaves it current; any torch-side in-place write to `self.params` bumps the
-    # tensor's version counter, a head shift goes through `shift_params` -- both invalidate.
+    # told that it is current.  DEFAULT: never told -- every entry point outside a captured replay rebuilds (one 8 us launch),
+    # and every captured replay rebuilds at its head (slimdqn/_graph.py), so a writer this class cannot see (a raw pointer, a
+    # DLPack consumer, `params.data.copy_()`: none of them moves torch's version counter) is still acted on.
+    # `trust_mirror = True` is an explicit declaration by the owner of the engine that every parameter write goes through
+    # torch operations on `self.params` or through this class: then the rebuild is skipped while (a) the call reads the
+    # engine's own buffer, (b) the last call left the mirror equal to it, (c) no torch operation has written the tensor since
+    # (version counter) and (d) tensor object and storage are the ones the engine allocated.
+    trust_mirror = os.environ.get("ISDQN_TRUST_MIRROR", "0") == "1"
+
     def _mirror_is_current(self, params) -> bool:
-        """Trust rule: the mirror is reused only when (a) the call reads the engine's own buffer, (b) the last call
-        of THIS engine left the mirror equal to it, (c) no torch operation has written the tensor since (version counter) and (d) the
-        tensor object and its storage are the ones the engine allocated (a rebound ``eng.params`` / ``.data`` is not trusted).  What
-        the counter cannot see -- a raw-pointer write from outside this class -- must call ``invalidate_mirror()``; every write this
-        package makes goes through torch ops or through the library calls below."""
-        return (params is None and getattr(self, "_mirror_version", None) == self.params._version
-                and self.params.data_ptr() == getattr(self, "_mirror_ptr", None))
+        return bool(self.trust_mirror and params is None and getattr(self, "_mirror_version", None) == self.params._version
+                    and self.params.data_ptr() == getattr(self, "_mirror_ptr", None))
+
+    def rebuild_mirror(self) -> None:
+        """Rebuild the weight mirror from the engine's parameters (one launch on the current stream), unconditionally."""
+        _hip.check(self.lib.isdqn_net_refresh_mirror(ctypes.byref(self.cfg), _hip.ptr(self.params), _hip.ptr(self.workspace),
+                                                     _hip.stream_ptr(self.device)), "isdqn_net_refresh_mirror")
+        self._mirror_made_current()
 
     def refresh_mirror(self) -> None:
         """Rebuild the weight mirror from the engine's parameters now (one launch on the current stream) unless it is current."""
         if self._mirror_is_current(None):
             return
-        _hip.check(self.lib.isdqn_net_refresh_mirror(ctypes.byref(self.cfg), _hip.ptr(self.params), _hip.ptr(self.workspace),
-                                                     _hip.stream_ptr(self.device)), "isdqn_net_refresh_mirror")
-        self._mirror_made_current()
+        self.rebuild_mirror()
 
     def invalidate_mirror(self) -> None:
         """Force the next call to rebuild the weight mirror from ``params`` (for writers that bypass torch's version counter)."""

@@ -57,10 +57,22 @@ class GraphedUpdate:
         # Every captured step takes the weight mirror as it is; run() rebuilds it in front of the replay (one eager 8 us launch) only
         # when the engine's bookkeeping says something wrote the parameters since the last call that left it current (consecutive
         # replays and acting in between do not: _engine.py _mirror_is_current).  (A second capture that rebuilds at its head was the
-        # first form of this; two graph executables over three streams crashed hipGraphLaunch -- hip::Graph::UpdateStreams -- in some
-        # test orders.)
+        # first form of this; it crashed hipGraphLaunch in hip::Graph::UpdateStreams in some test orders.  Cause, DESIGN.md
+        # "hipGraphLaunch fault": at launch the runtime fills the graph's stream array from the executable's own pool of
+        # parallel streams, skips every pool stream that maps to the launch stream's queue, and indexes the pool WITHOUT a bound:
+        # one skipped entry too many and it reads a Stream* past the end of the vector.  Which pool stream aliases the launch
+        # stream depends on how many streams the process created before the instantiation -- the test order.  The agents therefore
+        # keep ONE live executable each, destroy it before capturing a successor, and never re-instantiate in steady state.)
         self.graph = None
         self._capture()
+
+    def destroy(self) -> None:
+        """Release the executable graph (and the runtime's parallel streams it owns) after everything it enqueued has finished.
+        An agent calls this on the update object it replaces BEFORE it captures the successor."""
+        if self.graph is not None:
+            torch.cuda.synchronize(self.eng.device)
+            self.graph.reset()
+            self.graph = None
 
     def _make_batches(self) -> None:
         rb, eng = self.rb, self.eng
@@ -106,8 +118,12 @@ class GraphedUpdate:
         )
 
     def _steps(self) -> None:
-        """The S steps of one replay, enqueued on the current stream (the weight mirror must be current)."""
+        """The S steps of one replay, enqueued on the current stream.  The first node rebuilds the weight mirror from the parameters
+        as they are when the replay starts (whoever wrote them, however: _engine.py "weight-mirror bookkeeping"); the steps behind
+        it trust it -- each follows a learn step of the same replay, whose optimizer wrote both forms."""
         rb, eng = self.rb, self.eng
+        if not eng.trust_mirror:
+            eng.rebuild_mirror()
         if self.prioritized:
             tree = rb._sampling_distribution._sum_tree
             main, sampling = torch.cuda.current_stream(eng.device), self._sampling_stream
@@ -145,7 +161,7 @@ class GraphedUpdate:
         tree = self.rb._sampling_distribution._sum_tree if self.prioritized else None
         tree_state = [t.clone() for t in (tree._nodes_dev, tree._max_dev, tree._status)] if tree is not None else None
         with torch.cuda.stream(side):
-            self.eng.refresh_mirror()
+            self.eng.rebuild_mirror()
             self._steps()
         torch.cuda.current_stream(self.eng.device).wait_stream(side)
         torch.cuda.synchronize(self.eng.device)
@@ -168,11 +184,13 @@ class GraphedUpdate:
         rb._flush()
         if rb._frames.data_ptr() != self._frames_ptr:  # the frame store was re-allocated: pointers in the graph are stale
             self._frames_ptr = rb._frames.data_ptr()
+            self.destroy()
             self._make_batches()
             self._capture()
         sampler = rb._sampling_distribution
         rows = sampler.draw_rows_device(self.S, self.B)
         self.block.copy_(rows, non_blocking=True)
-        self.eng.refresh_mirror()  # (no launch when the mirror is current)
+        if self.eng.trust_mirror:
+            self.eng.refresh_mirror()  # (trusted engines only: one eager launch when the bookkeeping says the mirror is stale)
         self.graph.replay()
         self.eng._mirror_made_current()  # the last step's optimizer wrote both forms of the weights

@@ -29,6 +29,7 @@ from __future__ import annotations
 
 import json
 import os
+import select
 import subprocess
 import sys
 from multiprocessing import shared_memory
@@ -133,11 +134,23 @@ class VectorEnv:
             self._expect(p, b"R")
 
     # ------------------------------------------------------------------ plumbing
-    @staticmethod
-    def _expect(p, what: bytes) -> None:
+    WORKER_TIMEOUT_S = float(os.environ.get("ISDQN_WORKER_TIMEOUT_S", "300"))  # one command of one worker (a hung emulator must not hang the trainer)
+
+    @classmethod
+    def _expect(cls, p, what: bytes) -> None:
+        ready, _, _ = select.select([p.stdout], [], [], cls.WORKER_TIMEOUT_S)
+        if not ready:
+            p.kill()
+            raise RuntimeError(f"environment worker (pid {p.pid}) did not answer {what!r} within {cls.WORKER_TIMEOUT_S:.0f} s: killed "
+                               f"(its stderr is this process's stderr)")
         got = p.stdout.read(1)
         if got != what:
-            raise RuntimeError(f"environment worker (pid {p.pid}) died or answered {got!r} (exit code {p.poll()})")
+            try:
+                rc = p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                rc = None
+            raise RuntimeError(f"environment worker (pid {p.pid}) died or answered {got!r} instead of {what!r} (exit code {rc}; "
+                               f"its stderr is this process's stderr)")
 
     def _command(self, c: bytes) -> None:
         for p in self._workers:

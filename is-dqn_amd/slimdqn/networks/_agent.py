@@ -98,8 +98,8 @@ class EngineAgent:
             eng.adam_v.copy_(old.adam_v)
             eng.adam_count.copy_(old.adam_count)
             eng.losses_accum.copy_(old.losses_accum)
+        self._drop_graph()  # captured against the old engine's buffers
         self._engine = eng
-        self._graphed = None  # captured against the old engine's buffers
         self._ring = None
         self.params = DeviceParams(eng, eng.params)
         self.optimizer_state = {"count": eng.adam_count, "mu": eng.adam_m, "nu": eng.adam_v}
@@ -108,10 +108,17 @@ class EngineAgent:
     def _engine_changed(self, old) -> None:
         """Hook: a new engine replaced ``old`` (subclasses re-home extra device state)."""
 
-    def _graphed_update(self, replay_buffer, learn=None, key=None):
-        """The captured sample -> learn -> [write-back] step for this (replay, engine) pair, or None when the replay is not the device
-        replay of this GPU (reference-layout buffers take the eager path).  ``learn`` / ``key``: another learn call than the engine's
-        learn_on_batch and what it is bound to (DQN: the target parameters' buffer) -- a new key captures again."""
+    def _drop_graph(self) -> None:
+        """Destroy the live captured update, if any (one executable graph per agent: _graph.py, "hipGraphLaunch fault")."""
+        g, self._graphed = self._graphed, None
+        if g is not None:
+            g.destroy()
+
+    def _graphed_update(self, replay_buffer, learn=None, key=None, steps: int = 1):
+        """The captured sample -> learn -> [write-back] update of ``steps`` consecutive steps for this (replay, engine) pair, or None
+        when the replay is not the device replay of this GPU (reference-layout buffers take the eager path).  ``learn`` / ``key``:
+        another learn call than the engine's learn_on_batch and what it is bound to (DQN: the target parameters' buffer).  The agent
+        owns ONE executable graph at a time: a request that does not match the live one destroys it first, then captures."""
         if not getattr(self, "use_graph", True) or not hasattr(replay_buffer, "_d_elem_frames") or getattr(replay_buffer, "_lib", None) is None:
             return None
         if replay_buffer.add_count == 0:
@@ -122,11 +129,14 @@ class EngineAgent:
         prioritized = hasattr(replay_buffer._sampling_distribution, "_tree")
         writeback = bool(getattr(self, "priority_writeback", False))
         g = self._graphed
-        if g is None or g.rb is not replay_buffer or g.eng is not eng or g.writeback != (writeback and prioritized) or getattr(g, "key", None) != key:
+        if (g is None or g.rb is not replay_buffer or g.eng is not eng or g.writeback != (writeback and prioritized)
+                or getattr(g, "key", None) != key or g.S != steps):
             from slimdqn._graph import GraphedUpdate
 
-            g = self._graphed = GraphedUpdate(replay_buffer, eng, prioritized, steps_per_graph=1, writeback=writeback, learn=learn)
+            self._drop_graph()
+            g = self._graphed = GraphedUpdate(replay_buffer, eng, prioritized, steps_per_graph=steps, writeback=writeback, learn=learn)
             g.key = key
+            self._captures = getattr(self, "_captures", 0) + 1
         return g
 
     def _engine_for(self, batch_size: int) -> QNetEngine:
@@ -146,6 +156,10 @@ class EngineAgent:
             return {**{f"{k}/{m}": v for k, sub in tree.items() if k.startswith("Stack_") for m, v in sub.items()},
                     **{k: v for k, v in tree.items() if not k.startswith("Stack_")}}
 
+        # a model pickle `{"params": variables}` (get_model), the variables dict `{"params": tree[, "batch_stats": tree]}`
+        # (the reference's agent.params), or the bare tree
+        while isinstance(params.get("params"), dict) and isinstance(params["params"].get("params"), dict):
+            params = params["params"]
         tree = flatten(params["params"] if "params" in params else params)
         t = torch.empty_like(self._engine.params)
         self._engine.import_flax(tree, target=t, batch_stats=flatten(params.get("batch_stats")) if "params" in params else None)
@@ -346,6 +360,11 @@ class EngineAgent:
         return self._engine.forward(n_rows=1, params=self._bind(params), **self._obs_to_device(state))
 
     def get_model(self):
-        if self.batch_norm:  # Flax keeps the running averages in a second collection beside "params" (isdqn.py:87-88)
-            return {"params": self.params.to_flax(), "batch_stats": self.params.batch_stats()}
-        return {"params": self.params.to_flax()}
+        """The reference's `{"params": self.params}` (isdqn.py:137-138), where `self.params` is the full Flax variables dict that
+        `network.init` returned: `{"params": tree}` plus, for a BatchNorm network, the second collection `"batch_stats"` beside it
+        (isdqn.py:87-88).  The pickle the trainer writes is therefore `{"params": {"params": tree[, "batch_stats": tree]}}`, and
+        `network.apply(model["params"], ...)` works on it where JAX exists.  `_bind` loads either nesting back."""
+        variables = {"params": self.params.to_flax()}
+        if self.batch_norm:
+            variables["batch_stats"] = self.params.batch_stats()
+        return {"params": variables}

@@ -54,7 +54,7 @@ class DQN(EngineAgent):
             target = self._target_tensor(self.target_params)
             eng = self._engine_for(replay_buffer._batch_size) if hasattr(replay_buffer, "_batch_size") else self._engine
             g = self._graphed_update(replay_buffer, learn=lambda cb: eng.learn_on_batch_target(cb, target), key=target.data_ptr())
-            if g is not None:  # (captured against THIS target copy: update_target_params makes a new one, which captures again)
+            if g is not None:  # (captured against the target BUFFER: update_target_params refreshes it in place, nothing is captured again)
                 g.run()
                 return
             batch_samples = replay_buffer.sample()
@@ -63,7 +63,9 @@ class DQN(EngineAgent):
 
     def update_target_params(self, step: int):
         if step % self.target_update_frequency == 0:
-            self.target_params = self.params.copy()
+            # `self.target_params = self.params.copy()` (dqn.py:50) as an in-place refresh of ONE persistent buffer: the captured
+            # step reads the target through a fixed pointer, so a target update neither re-captures nor re-instantiates a graph
+            self.target_params.tensor.copy_(self.params.tensor)
             eng = self._engine
             self.cumulated_loss = self.cumulated_loss + float(eng.losses_accum.cpu().numpy()[0])
             eng.losses_accum.zero_()

@@ -71,28 +71,28 @@ class iSDQN(EngineAgent):
         ~280 us each -- about what the GPU needs for the step)."""
         if n_steps <= 0:
             return
-        g1 = self._graphed_update(replay_buffer)
-        if g1 is None or n_steps == 1:
+        # ONE executable graph per agent (networks/_agent.py): the round's step count selects what is captured.  A caller that keeps
+        # changing it (a handful of captures) gets replays of whatever is live, or single-step replays, instead of a capture per call.
+        live, settled = self._graphed, getattr(self, "_captures", 0) >= 8
+        if live is not None and live.rb is replay_buffer and n_steps % live.S == 0 and (live.S == n_steps or settled):
+            steps = live.S
+        else:
+            steps = 1 if settled else n_steps
+        g = self._graphed_update(replay_buffer, steps=steps)
+        if g is None:
             for _ in range(n_steps):
                 self.update_online_params(0, replay_buffer)
             return
-        many = getattr(self, "_graphed_many", None)
-        if many is None or many[0] is not g1:
-            many = self._graphed_many = (g1, {})
-        g = many[1].get(n_steps)
-        if g is None:
-            if len(many[1]) >= 4:  # (rounds owe a constant number of steps; a changing one takes single-step replays)
-                for _ in range(n_steps):
-                    g1.run()
-                return
-            from slimdqn._graph import GraphedUpdate
-
-            g = many[1][n_steps] = GraphedUpdate(g1.rb, g1.eng, g1.prioritized, steps_per_graph=n_steps, writeback=g1.writeback)
-        g.run()
+        for _ in range(n_steps // g.S):
+            g.run()
 
     def update_online_params(self, step: int, replay_buffer):
         if step % self.data_to_update == 0:
-            g = self._graphed_update(replay_buffer)
+            live = self._graphed
+            if live is not None and live.S > 1 and live.rb is replay_buffer:  # learn_steps' capture is the live graph: eager step
+                g = None
+            else:
+                g = self._graphed_update(replay_buffer)
             if g is not None:
                 g.run()  # same draws, same kernels, same bits as the eager branch below (tests/test_gpu_graphed_update.py)
                 return

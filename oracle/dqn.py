@@ -85,9 +85,10 @@ class _OneHead:
         return int(torch.argmax(self.apply(params, torch.as_tensor(np.asarray(state))[None], use_running_average=self.batch_norm)[0]))
 
     def get_model(self):
+        # the reference pickles `{"params": self.params}` with self.params the full Flax variables dict (isdqn.py:137-138)
         if self.batch_norm:
-            return {"params": net.to_numpy(self.params), "batch_stats": net.to_numpy(self.batch_stats)}
-        return {"params": net.to_numpy(self.params)}
+            return {"params": {"params": net.to_numpy(self.params), "batch_stats": net.to_numpy(self.batch_stats)}}
+        return {"params": {"params": net.to_numpy(self.params)}}
 
 
 class DQN(_OneHead):

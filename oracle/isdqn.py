@@ -197,6 +197,7 @@ class iSDQN:
         return int(torch.argmax(q[1 + idx_network]))
 
     def get_model(self):
+        # the reference pickles `{"params": self.params}` with self.params the full Flax variables dict (isdqn.py:137-138)
         if self.batch_norm:
-            return {"params": net.to_numpy(self.params), "batch_stats": net.to_numpy(self.batch_stats)}
-        return {"params": net.to_numpy(self.params)}
+            return {"params": {"params": net.to_numpy(self.params), "batch_stats": net.to_numpy(self.batch_stats)}}
+        return {"params": {"params": net.to_numpy(self.params)}}

@@ -61,8 +61,8 @@ def test_training_run_matches_oracle_agent_and_replay():
             # by a few 1e-3 (Adam normalises near-zero gradients to +-lr); the first log is held to 1e-3
             tol = 1e-3 if lh is logs_h[0] else 5e-3
             assert abs(lh[k] - lo[k]) < tol * max(1.0, abs(lo[k])), (k, lh[k], lo[k])
-    got = hip.get_model()["params"]
-    exp = ora.get_model()["params"]
+    got = hip.get_model()["params"]["params"]
+    exp = ora.get_model()["params"]["params"]
     for mod in exp:
         for leaf in exp[mod]:
             assert got[mod][leaf].shape == exp[mod][leaf].shape
@@ -85,15 +85,23 @@ def test_reference_layout_batches_and_functional_signatures():
     assert abs(float(loss_h) - float(loss_o)) < 1e-3 * max(1.0, abs(float(loss_o)))
     np.testing.assert_allclose(per_head_h.cpu().numpy(), per_head_o.detach().numpy(), atol=1e-3)
     # a pytree handed in from outside is honoured
-    tree = ora.get_model()
+    tree = ora.get_model()["params"]
     loss_t, _ = hip.loss_on_batch(tree, s)
     assert abs(float(loss_t) - float(loss_o)) < 1e-3 * max(1.0, abs(float(loss_o)))
+    # ... in every nesting a reference user can hold: the model pickle {"params": variables} (isdqn.py:137-138) after a pickle
+    # round trip, the variables dict {"params": tree} (the reference's agent.params), the bare tree
+    model = pickle.loads(pickle.dumps(ora.get_model()))
+    assert set(model) == {"params"} and set(model["params"]) == {"params"} and "Conv_0" in model["params"]["params"]
+    for handed in (model, model["params"], model["params"]["params"]):
+        loss_p, _ = hip.loss_on_batch(handed, s)
+        assert float(loss_p) == float(loss_t)
+    assert set(hip.get_model()) == {"params"} and set(hip.get_model()["params"]) == {"params"}
     p, st, losses = hip.learn_on_batch(hip.params, hip.optimizer_state, s)
     assert p is hip.params and losses.shape == (K,)
     # shift on an external copy leaves the agent's parameters alone (shift_params is functional in the reference)
-    before = hip.get_model()["params"]["Dense_1"]["bias"].copy()
+    before = hip.get_model()["params"]["params"]["Dense_1"]["bias"].copy()
     shifted = hip.shift_params(hip.params.clone())
-    np.testing.assert_array_equal(hip.get_model()["params"]["Dense_1"]["bias"], before)
+    np.testing.assert_array_equal(hip.get_model()["params"]["params"]["Dense_1"]["bias"], before)
     np.testing.assert_array_equal(shifted["params"]["Dense_1"]["bias"][:-A], before[A:])
     # compute_target formula (test_isdqn.py:51-63)
     nq = torch.randn(K, A)
@@ -114,7 +122,8 @@ def test_best_action_follows_head_choice():
 
 
 def test_acting_path_frame_ring_and_weight_mirror_reuse():
-    """The acting path keeps the frame stack on the device as a ring (one 7 KB frame uploaded per step) and reuses the
+    """The acting path keeps the frame stack on the device as a ring (one 7 KB frame uploaded per step) and -- on a TRUSTED engine
+    (trust_mirror, set here; the default rebuilds in every call) -- reuses the
     workspace's pre-split weights while nothing has written the parameters: both must be invisible -- every action equals
     the argmax of a fresh full forward, across rolls, a reset, a learn step, a torch-side parameter write and a head shift."""
     from slimdqn._engine import QNetEngine
@@ -125,6 +134,7 @@ def test_acting_path_frame_ring_and_weight_mirror_reuse():
     K, A, B = 3, 5, 8
     hip, _ = _agents(K, A, B)
     eng = hip._engine
+    eng.trust_mirror = True
     # the checker: a second engine (own workspace, own weight mirror) run on the agent's parameter buffer
     chk = QNetEngine((84, 84, 4), A, 1 + K, FEATS, "cnn", True, B, gamma_n=0.99, learning_rate=2e-4, adam_eps=1.5e-4)
     env = SyntheticAtariEnv("Synthetic", n_actions=A, seed=3, episode_length=9)
@@ -156,6 +166,34 @@ def test_acting_path_frame_ring_and_weight_mirror_reuse():
             hip.shift_params(hip.params)
             assert not eng._mirror_is_current(None)
     assert reused >= 20 and 3 <= fulls <= 8  # most steps reuse the mirror; full uploads only at episode starts
+
+
+def test_default_acting_sees_writes_the_version_counter_cannot():
+    """Default engines rebuild the weight mirror in every acting call: a write through `.data` (no version bump) between two
+    one-frame-shift steps -- the hipGraph acting path -- must change the action exactly as a fresh full forward says."""
+    from slimdqn._engine import QNetEngine
+    from slimdqn.environments.synthetic import SyntheticAtariEnv
+
+    K, A, B = 3, 5, 8
+    hip, _ = _agents(K, A, B)
+    eng = hip._engine
+    assert not eng.trust_mirror
+    chk = QNetEngine((84, 84, 4), A, 1 + K, FEATS, "cnn", True, B, gamma_n=0.99, learning_rate=2e-4, adam_eps=1.5e-4)
+    env = SyntheticAtariEnv("Synthetic", n_actions=A, seed=5, episode_length=50)
+    env.reset()
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    for t in range(24):
+        state = env.state
+        if t >= 4 and t % 2 == 0:  # a new random head matrix behind torch's back
+            v = eng.params._version
+            noise = torch.randn(eng.params.shape, generator=gen).to(eng.device)
+            eng.params.data.add_(0.05 * noise)
+            assert eng.params._version == v
+        action = hip.best_action(hip.params, state, key=t % K)
+        q = chk.forward(n_rows=1, params=eng.params, **_planes(state, eng.device)).cpu().numpy().reshape(1 + K, A)
+        assert action == int(np.argmax(q[1 + t % K])), t
+        env.step(action)
+    assert hip._ring is not None and hip._ring["shifts"] > 10  # the one-frame-shift graph path ran
 
 
 def _planes(state, device):
@@ -232,7 +270,7 @@ def test_entry_point_end_to_end_on_synthetic_env(tmp_path, prioritized):
     assert params["shared_parameters"]["features"] == [8, 8, 8, 16] and params["isdqn"]["n_bellman_iterations"] == 2
     res = json.load(open(out / "isdqn" / "episode_returns_and_lengths" / "1.json"))
     assert len(res["episode_returns"]) == 2
-    model = pickle.load(open(out / "isdqn" / "models" / "1", "rb"))
+    model = pickle.load(open(out / "isdqn" / "models" / "1", "rb"))["params"]
     assert model["params"]["Conv_0"]["kernel"].shape == (8, 8, 4, 8)
     assert model["params"]["Dense_1"]["kernel"].shape == (16, 3 * 9)
     with pytest.raises(AssertionError):  # same seed again: refused (experiments/base/utils.py:46-51)
@@ -347,7 +385,7 @@ def test_lunar_lander_entry_point_end_to_end(tmp_path):
     out = tmp_path / "lunar_lander" / "exp_output" / "test_ll"
     params = json.load(open(out / "parameters.json"))
     assert params["shared_parameters"]["features"] == [100, 100] and params["isdqn"]["n_bellman_iterations"] == 1
-    model = pickle.load(open(out / "isdqn" / "models" / "1", "rb"))
+    model = pickle.load(open(out / "isdqn" / "models" / "1", "rb"))["params"]
     assert model["params"]["Dense_0"]["kernel"].shape == (8, 100) and model["params"]["Dense_2"]["kernel"].shape == (100, 2 * 4)
 
 
@@ -369,7 +407,7 @@ def test_reference_atari_test_settings_on_the_synthetic_environment(tmp_path, al
     out = tmp_path / "atari" / "exp_output" / f"_test_{algo}_Pong" / algo
     res = json.load(open(out / "episode_returns_and_lengths" / "1.json"))
     assert len(res["episode_returns"]) == 1
-    model = pickle.load(open(out / "models" / "1", "rb"))
+    model = pickle.load(open(out / "models" / "1", "rb"))["params"]
     assert model["params"]["Conv_2"]["kernel"].shape == (3, 3, 3, 1) and model["params"]["Dense_0"]["kernel"].shape == (11 * 11 * 1, 15)
     assert all(np.isfinite(v).all() for leaves in model["params"].values() for v in leaves.values())
 
@@ -388,6 +426,6 @@ def test_reference_lunar_lander_test_settings(tmp_path, algo):
     run(argv, root=str(tmp_path))
     out = tmp_path / "lunar_lander" / "exp_output" / f"_test_{algo}" / algo
     assert len(json.load(open(out / "episode_returns_and_lengths" / "1.json"))["episode_returns"]) == 1
-    model = pickle.load(open(out / "models" / "1", "rb"))
+    model = pickle.load(open(out / "models" / "1", "rb"))["params"]
     assert model["params"]["Dense_0"]["kernel"].shape == (8, 25) and model["params"]["Dense_1"]["kernel"].shape == (25, 15)
     assert all(np.isfinite(v).all() for leaves in model["params"].values() for v in leaves.values())

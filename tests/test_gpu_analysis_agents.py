@@ -295,5 +295,5 @@ def test_analysis_entry_points_with_the_batch_norm_flag(tmp_path, algo):
     run(argv, root=str(tmp_path))
     out = tmp_path / "atari" / "exp_output" / "anabn_Synthetic"
     assert json.load(open(out / "parameters.json"))[algo]["batch_norm"] is True
-    model = pickle.load(open(out / algo / "models" / "1", "rb"))
+    model = pickle.load(open(out / algo / "models" / "1", "rb"))["params"]
     assert set(model) == {"params", "batch_stats"} and np.isfinite(model["batch_stats"]["BatchNorm_0"]["mean"]).all()

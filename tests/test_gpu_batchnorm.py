@@ -206,7 +206,7 @@ def test_agent_with_batchnorm_trains_acts_and_exports_like_the_oracle_agent():
 
     K, A, B, feats = 2, 4, 8, [8, 16, 16, 32]
     agent = iSDQN(0, (84, 84, 4), A, K, feats, True, True, "cnn", 1e-3, 0.99, 1, 1, 6, adam_eps=1.5e-4, batch_size=B)
-    model = agent.get_model()
+    model = agent.get_model()["params"]
     assert set(model) == {"params", "batch_stats"} and model["batch_stats"]["BatchNorm_0"]["var"].shape == (84, 84)
     assert model["params"]["BatchNorm_3"]["scale"].shape == (11 * 11 * 16,) and model["params"]["Conv_0"]["kernel"].shape == (8, 8, 4, 8)
     oracle = Oracle(0, (84, 84, 4), A, K, feats, True, True, "cnn", 1e-3, 0.99, 1, 1, 6, adam_eps=1.5e-4, params=model["params"])
@@ -233,14 +233,14 @@ def test_agent_with_batchnorm_trains_acts_and_exports_like_the_oracle_agent():
         assert np.abs(got - exp).max() < tol * max(1.0, np.abs(exp).max()), (i, got, exp)
     acc = agent._engine.losses_accum.cpu().numpy()
     np.testing.assert_allclose(acc, np.sum([g for g, _ in per_step], axis=0), rtol=1e-5)  # the device accumulator (isdqn.py:62)
-    stats = agent.get_model()["batch_stats"]
+    stats = agent.get_model()["params"]["batch_stats"]
     for m, l in oracle.batch_stats.items():
         for n, t in l.items():
             assert np.abs(stats[m][n] - t.numpy()).max() < 5e-3 * max(1.0, float(t.abs().max())), (m, n)  # (four drifting steps, see above)
     # acting (isdqn.py:127-135, use_running_average=True) on the ORACLE's trained model, handed over as the reference's pytree
     # {"params", "batch_stats"}: no trajectory drift between the two sides, so the 1e-3 bar applies
     state = rng.integers(0, 256, (84, 84, 4), dtype=np.uint8)
-    o_model = oracle.get_model()
+    o_model = oracle.get_model()["params"]
     q_all = oracle.apply(oracle.params, torch.tensor(state)[None], use_running_average=True)[0].detach().numpy()
     q_a = agent.q_values(o_model, state)
     assert np.abs(q_a - q_all).max() < 1e-3 * max(1.0, np.abs(q_all).max())
@@ -262,7 +262,7 @@ def test_tfdqn_with_batchnorm_matches_the_oracle():
 
     A, B, feats = 4, 8, [8, 16, 16, 32]
     agent = TFDQN(0, (84, 84, 4), A, feats, True, True, "cnn", 1e-3, 0.99, 1, 1, 6, adam_eps=1.5e-4, batch_size=B)
-    model = agent.get_model()
+    model = agent.get_model()["params"]
     assert set(model) == {"params", "batch_stats"}
     oracle = Oracle(0, (84, 84, 4), A, feats, True, True, "cnn", 1e-3, 0.99, 1, 1, 6, adam_eps=1.5e-4, params=model["params"])
     _frames, _ids, _a, _r, _t, ref = make_frame_batch(B, A, seed=21)
@@ -271,11 +271,11 @@ def test_tfdqn_with_batchnorm_matches_the_oracle():
     _, _, loss = agent.learn_on_batch(agent.params, agent.optimizer_state, ref)
     got = float(loss.cpu().numpy().reshape(-1)[0])
     assert abs(got - o_loss) < 1e-3 * max(1.0, abs(o_loss)) and abs(o_loss - o_loss2) < 1e-12
-    after = agent.get_model()
+    after = agent.get_model()["params"]
     for m, l in oracle.batch_stats.items():
         for n, t in l.items():
             assert np.abs(after["batch_stats"][m][n] - t.numpy()).max() < 2e-5 * max(1.0, float(t.abs().max())), (m, n)
-    exp = oracle.get_model()["params"]
+    exp = oracle.get_model()["params"]["params"]
     for m in exp:
         for n in exp[m]:
             assert np.abs(after["params"][m][n] - exp[m][n]).max() < 2.001e-3, (m, n)  # one Adam step of lr = 1e-3
@@ -299,7 +299,7 @@ def test_entry_points_with_the_batch_norm_flag(tmp_path, algo, arch):
     run(argv, root=str(tmp_path))
     out = tmp_path / "atari" / "exp_output" / name
     assert json.load(open(out / "parameters.json"))[algo]["batch_norm"] is True  # (an agent parameter: parser_argument.py:27-36)
-    model = pickle.load(open(out / algo / "models" / "1", "rb"))
+    model = pickle.load(open(out / algo / "models" / "1", "rb"))["params"]
     assert set(model) == {"params", "batch_stats"}
     stats = model["batch_stats"]
     top = stats["BatchNorm_0"]

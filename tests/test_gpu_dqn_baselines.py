@@ -79,7 +79,7 @@ def test_loss_targets_and_adam_steps_match_the_oracle(kind, shape):
             _, _, h_loss = hip.learn_on_batch(hip.params, hip.optimizer_state, _as_device_batch(hip, batch))
         # (after an update two fp32-class trajectories drift: Adam moves rounding-level gradients by a full +-lr)
         assert abs(float(h_loss) - o_loss) < (1e-3 if step == 0 else 5e-3) * max(1.0, abs(o_loss)), f"step {step}"
-    got = hip.get_model()["params"]
+    got = hip.get_model()["params"]["params"]
     for mod in p:
         for leaf in p[mod]:
             # three Adam steps of size lr: entries with rounding-level gradients may move the other way (see test_gpu_network.py)
@@ -265,7 +265,7 @@ def test_fc_plans_of_the_baselines_match_the_oracle(kind, plan):
             p, s_opt, o_loss = ora.learn_on_batch(p, s_opt, ref)
             h_loss = eng.learn_on_batch(batch).cpu().numpy()[0]
         assert abs(float(h_loss) - o_loss) < (1e-3 if step == 0 else 5e-3) * max(1.0, abs(o_loss)), f"step {step}"
-    got = hip.get_model()["params"]
+    got = hip.get_model()["params"]["params"]
     for mod in p:
         for leaf in p[mod]:
             assert np.abs(got[mod][leaf] - p[mod][leaf].numpy()).max() < 3 * 2.001e-3, (mod, leaf)

@@ -39,11 +39,13 @@ def test_graph_replay_equals_eager_steps(workload):
 
 
 def test_trusted_graph_only_while_the_mirror_is_current():
-    """Every captured step takes the weight mirror as it is; GraphedUpdate.run() rebuilds it in front of the replay only when the
-    engine's bookkeeping (_engine.py: _mirror_is_current) says something wrote the parameters since the last replay.  A torch-side
+    """The opt-in trusted mode (engine.trust_mirror = True: the owner declares that every parameter write goes through torch or the
+    engine): every captured step takes the weight mirror as it is and GraphedUpdate.run() rebuilds it in front of the replay only when
+    the engine's bookkeeping (_engine.py: _mirror_is_current) says something wrote the parameters since the last replay.  A torch-side
     write and a head shift between replays must both be seen by the next replay."""
     S = 3
     eager, graphed = _replica("c2"), _replica("c2")
+    graphed.eng.trust_mirror = True
     graphed.enable_graph(S)
     g = graphed.graphed
     used = []
@@ -60,6 +62,42 @@ def test_trusted_graph_only_while_the_mirror_is_current():
         g.run()
     torch.cuda.synchronize()
     assert used == [False, True, False, True, False]
+    for name in ("params", "adam_m", "adam_v", "adam_count", "losses_accum"):
+        a, b = getattr(eager.eng, name), getattr(graphed.eng, name)
+        assert torch.equal(a, b), f"{name}: {(a != b).sum().item()} elements differ between eager and graph replay"
+
+
+def test_default_replay_sees_writes_the_version_counter_cannot():
+    """Default (engine.trust_mirror False): a replay rebuilds the weight mirror at its head, so parameters written behind torch's
+    back -- through `.data` (its own version counter) and through a raw device pointer (hipMemcpy) -- are the ones the next replay
+    trains on: bit-identical with the eager loop, which rebuilds in every call."""
+    import ctypes
+    import os
+
+    hip_rt = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))  # the runtime torch itself loaded
+    S = 2
+    eager, graphed = _replica("c2"), _replica("c2")
+    assert not graphed.eng.trust_mirror
+    graphed.enable_graph(S)
+    g = graphed.graphed
+    for replay in range(4):
+        if replay == 1:
+            for r in (eager, graphed):
+                v = r.eng.params._version
+                r.eng.params.data.mul_(1.0009765625)  # `.data` shares the storage, not the version counter
+                assert r.eng.params._version == v
+        if replay == 2:
+            for r in (eager, graphed):
+                v = r.eng.params._version
+                host = (r.eng.params[:4096] * 0.5).cpu().contiguous()
+                torch.cuda.synchronize()
+                rc = hip_rt.hipMemcpy(ctypes.c_void_p(r.eng.params.data_ptr()), ctypes.c_void_p(host.data_ptr()),
+                                      ctypes.c_size_t(host.numel() * 4), 1)  # hipMemcpyHostToDevice through the raw pointer
+                assert rc == 0 and r.eng.params._version == v
+        for _ in range(S):
+            eager.step()
+        g.run()
+    torch.cuda.synchronize()
     for name in ("params", "adam_m", "adam_v", "adam_count", "losses_accum"):
         a, b = getattr(eager.eng, name), getattr(graphed.eng, name)
         assert torch.equal(a, b), f"{name}: {(a != b).sum().item()} elements differ between eager and graph replay"
@@ -117,8 +155,9 @@ def test_agent_update_online_params_graphed_equals_eager(prioritized):
 
 @pytest.mark.parametrize("arch, batch_norm", [("cnn", True), ("impala", False), ("impala", True), ("fc", False), ("fc", True)])
 def test_captured_step_equals_eager_on_the_other_learn_paths(arch, batch_norm):
-    """The captured one-step graph (networks/_agent.py _graphed_update) replays WITHOUT rebuilding the weight mirror whenever the
-    engine's bookkeeping says the previous call left it current (slimdqn/_graph.py), so the optimizer launches of the BatchNorm path,
+    """Steps 2..S of a captured replay take the weight mirror as the previous step's optimizer left it (slimdqn/_graph.py), and a
+    trusted engine (trust_mirror, set here) replays WITHOUT rebuilding whenever its bookkeeping says the previous call left it current,
+    so the optimizer launches of the BatchNorm path,
     of the impala torso and of the all-dense plan have to leave the mirror equal to the parameters they wrote; the fc step also
     materialises its float32 observation rows inside the graph.  Two agents, one with use_graph=False, same stream: bit-identical after
     every update."""
@@ -131,6 +170,7 @@ def test_captured_step_equals_eager_on_the_other_learn_paths(arch, batch_norm):
 
     def make(use_graph):
         agent = iSDQN(0, obs, A, K, feats, True, batch_norm, arch, 2e-4, 0.99, 1, 1, 5, adam_eps=1.5e-4, batch_size=B, use_graph=use_graph)
+        agent._engine.trust_mirror = True
         rb = ReplayBuffer(UniformSamplingDistribution(5), B, C, stack_size=(1 if arch == "fc" else obs[2]), update_horizon=1, gamma=0.99)
         return agent, rb
 

@@ -164,7 +164,7 @@ def test_impala_agent_surface_and_nested_model_export():
     from slimdqn.networks.isdqn import iSDQN
 
     agent = iSDQN(0, (84, 84, 4), 4, 2, [8, 8, 8, 16], True, False, "impala", 1e-3, 0.99, 1, 1, 4, batch_size=4)
-    model = agent.get_model()["params"]
+    model = agent.get_model()["params"]["params"]
     # Flax nests the Stack's modules (dqn.py:7-36): params["Stack_1"]["Conv_3"]["kernel"]
     assert model["Stack_1"]["Conv_3"]["kernel"].shape == (3, 3, 8, 8) and model["Stack_0"]["Conv_0"]["kernel"].shape == (3, 3, 4, 8)
     assert model["Stack_2"]["LayerNorm_1"]["scale"].shape == (8,) and model["LayerNorm_0"]["scale"].shape == (8,)
@@ -186,5 +186,5 @@ def test_entry_point_with_the_impala_torso(tmp_path):
     assert len(gathered) == 1
     out = tmp_path / "atari" / "exp_output" / "imp_Synthetic"
     assert json.load(open(out / "parameters.json"))["shared_parameters"]["architecture_type"] == "impala"
-    model = pickle.load(open(out / "isdqn" / "models" / "1", "rb"))
+    model = pickle.load(open(out / "isdqn" / "models" / "1", "rb"))["params"]
     assert model["params"]["Stack_2"]["Conv_4"]["kernel"].shape == (3, 3, 8, 8)

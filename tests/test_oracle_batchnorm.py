@@ -129,7 +129,7 @@ def test_learn_moves_the_running_averages_and_only_acting_reads_them():
             np.testing.assert_allclose(ag.batch_stats[name]["mean"].numpy(), 0.01 * mean.numpy(), rtol=1e-10, atol=1e-12)
         else:
             assert float((ag.batch_stats[name]["var"] - 1.0).abs().max()) > 0.0
-        assert set(ag.get_model()) == {"params", "batch_stats"}
+        assert set(ag.get_model()["params"]) == {"params", "batch_stats"}
 
 
 def test_grad_against_finite_differences_with_batch_norm():

@@ -61,3 +61,49 @@ def test_terminal_before_horizon_is_absorbing():
     flags = [s.step([0])[2:] for _ in range(10)]
     assert [bool(a[0]) for a, _ in flags] == [False] * 4 + [True] + [False] * 4 + [True]
     assert [bool(e[0]) for _, e in flags] == [bool(a[0]) for a, _ in flags]
+
+
+def _helper_spec(cls):
+    import os
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    os.environ["PYTHONPATH"] = here + os.pathsep + os.environ.get("PYTHONPATH", "")  # the workers' import path
+    if here not in sys.path:
+        sys.path.insert(0, here)  # the parent builds one environment itself (action count, frame geometry)
+    return dict(module="helpers.chatty_env", **{"class": cls}, kwargs=dict(name="X", n_actions=6, episode_length=23), seed_kw="seed", seed0=5,
+                seed_step=1000)
+
+
+def test_worker_protocol_survives_an_environment_that_prints_on_stdout():
+    """The emulator stack's own stdout (ALE / gymnasium banners, warnings, raw writes to descriptor 1) must not reach the one-byte
+    protocol: the worker keeps a private duplicate of the pipe and points descriptor 1 at stderr (environments/_worker.py)."""
+    from slimdqn.environments.synthetic import SyntheticAtariEnv
+    from slimdqn.environments.vector import VectorEnv
+
+    n = 3
+    v = VectorEnv(make_env=_helper_spec("ChattyEnv"), n_envs=n, n_workers=2, horizon=17)
+    try:
+        s = VectorEnv([SyntheticAtariEnv("X", 6, seed=5 + 1000 * i, episode_length=23) for i in range(n)], horizon=17)
+        s.reset()
+        rng = np.random.default_rng(1)
+        for _ in range(20):
+            a = rng.integers(0, 6, n)
+            for x, y in zip(v.step(a), s.step(a)):
+                np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(v.planes, s.planes)
+    finally:
+        v.close()
+
+
+def test_a_hung_worker_raises_instead_of_hanging_the_trainer(monkeypatch):
+    import pytest
+
+    from slimdqn.environments.vector import VectorEnv
+
+    monkeypatch.setattr(VectorEnv, "WORKER_TIMEOUT_S", 2.0)
+    v = VectorEnv(make_env=_helper_spec("HungEnv"), n_envs=2, n_workers=1, horizon=17)
+    try:
+        with pytest.raises(RuntimeError, match="did not answer"):
+            v.step(np.zeros(2, dtype=np.int64))
+    finally:
+        v.close()
