@@ -265,6 +265,30 @@ def spawn_ranks(n_gpus: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def partitioned_streams(R: int, device):
+    """R HIP streams whose kernels run on disjoint R-ths of the GPU's compute units (hipExtStreamCreateWithCUMask through the runtime
+    torch itself loaded; bit b of the mask is CU b // n_xcd of XCD b % n_xcd on MI355X -- profiles/round4/cu_mask_probe.txt -- so a
+    contiguous range of bits is the same share of every XCD, which the runtime requires: a mask that leaves an XCD empty is ignored)."""
+    import ctypes
+
+    import torch
+
+    rt = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    assert n_cu % R == 0, f"{n_cu} compute units do not split into {R} equal shares"
+    words = (n_cu + 31) // 32
+    out = []
+    for r in range(R):
+        mask = (ctypes.c_uint32 * words)()
+        for b in range(r * n_cu // R, (r + 1) * n_cu // R):
+            mask[b // 32] |= 1 << (b % 32)
+        h = ctypes.c_void_p()
+        rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+        assert rc == 0 and h.value, f"hipExtStreamCreateWithCUMask failed ({rc})"
+        out.append(torch.cuda.ExternalStream(h.value, device=device))
+    return out
+
+
 def steps_per_graph(steps: int, limit: int) -> int:
     """Largest S <= limit dividing the timed step count (a graph replays S steps at a time: the timed region is EXACTLY `steps`) that
     leaves at least four replays in it -- launching a replay overlaps the previous one's execution; ONE 20-step replay measured 3 460 -
@@ -294,6 +318,9 @@ def main():
     ap.add_argument("--replay-stats", type=int, default=200, help="graph replays timed one by one after the run (0 = skip)")
     ap.add_argument("--replicas-per-gpu", type=int, default=1, help="independent replicas sharing each GPU on their own streams, as the "
                     "reference shares one GPU between seeds (launch_job/atari/normal/train.sh:9-16); the headline number is 1")
+    ap.add_argument("--cu-partition", action="store_true", help="with --replicas-per-gpu R: every replica's stream gets its own 1/R of the "
+                    "compute units (hipExtStreamCreateWithCUMask: CUs [r*n/R, (r+1)*n/R) of the mask's order, i.e. the same share of every "
+                    "XCD), so the replicas run side by side instead of time-slicing the whole chip")
     args = ap.parse_args()
     assert args.steps >= 1 and args.warmup >= 0 and args.gpus >= 1
 
@@ -342,7 +369,7 @@ def main():
     if R == 1:
         one = (lambda: rep.graphed.run()) if rep.graphed is not None else rep.step
     else:  # every replica on its own stream: their kernels interleave on the GPU (a "step" below is one step of EVERY replica)
-        streams = [torch.cuda.Stream(device) for _ in reps]
+        streams = partitioned_streams(R, device) if args.cu_partition else [torch.cuda.Stream(device) for _ in reps]
 
         def one():
             for x, st in zip(reps, streams):
@@ -421,7 +448,7 @@ def main():
             "dtype": "bf16x3 (split-bf16 MFMA operands hi+lo, fp32 accumulate)" if args.precision == "bf16x3" else "bf16 (single pass, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": w["desc"], "replay_capacity": args.capacity, "precision": args.precision,
-                       "launch": f"hipGraph x{S} steps" if rep.graphed is not None else "eager", "replicas": world * R, "replicas_per_gpu": R, "parallelism": f"independent-seed replicas x{world * R}"},
+                       "launch": f"hipGraph x{S} steps" if rep.graphed is not None else "eager", "replicas": world * R, "replicas_per_gpu": R, "cu_partition": bool(args.cu_partition and R > 1), "parallelism": f"independent-seed replicas x{world * R}"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,

@@ -1211,6 +1211,11 @@ static int launch_conv_fwd(const Layer& l, const float* params, const float* wmi
 static int conv_fwd_img(const Layer& l, bool x3, const float* params, const float* wmir, const NetInput& in, const float* act_in, int n_img,
                         int z_img, float* act, float* z, hipStream_t st, bool* done) {
     *done = false;
+    // The image-resident kernels store `act` unconditionally (only the `z` store is guarded, by z_img): a caller without an activation
+    // output -- the impala Stacks pass act == nullptr for the convolutions whose output is only needed pre-activation -- must take the
+    // generic engine.  (Round 3's uncommitted experiment that routed the impala convolutions here faulted on exactly that store:
+    // "Memory access fault ... on address 0x9000" = null + the first image tile's offset, gpurun_out/imp1.log)
+    if (act == nullptr || (z == nullptr && z_img > 0)) return ISDQN_OK;
     ConvImgParams ip;
     ip.g = conv_geom(l);
     // (two channel tiles: the kernel then alternates two accumulator sets, see conv_fwd_img_kernel)
@@ -1582,7 +1587,14 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
     dp.n_img = n_img;
     dp.T = l.ksz / l.stride;
     dp.Kc = dp.T * dp.T * l.cout_p;
+    // top / left zero border of the dz image: the taps of a class reach dz rows (iy + pad - py) / stride - jy, jy < T, i.e. down
+    // to pad / stride - (T - 1).  (Round 1 took T - 1 rows whatever the padding; for the 3x3 / 1 layer that is one row and one
+    // column too many -- a 14 x 14 instead of a 13 x 13 image, 83 KB of LDS instead of 75: ONE workgroup per CU instead of two.)
+#if defined(ISDQN_DGRAD_WIDE_BORDER)
     dp.bt = dp.T - 1;
+#else
+    dp.bt = dp.T - 1 - l.pad / l.stride > 0 ? dp.T - 1 - l.pad / l.stride : 0;
+#endif
     const int need_h = (l.hin - 1 + l.pad) / l.stride + 1, need_w = (l.win - 1 + l.pad) / l.stride + 1;
     dp.Hd = dp.bt + (l.hout > need_h ? l.hout : need_h);
     dp.Wd = dp.bt + (l.wout > need_w ? l.wout : need_w);
