@@ -383,7 +383,13 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
                 if (ntw) {
                     int ncg = l.K / (64 * ntw);
                     int G = (P.Bb * ncg + 255) / 256;
-                    if (wide) G = (P.Bb + 127) / 128;  // ~128 workgroups of two images: measured best (1: 2681, 2: 2806 steps/s)
+                    // two images per workgroup at the headline batch (measured best, 1: 2681, 2: 2806 steps/s: 128 workgroups share
+                    // the CUs with the data-gradient chain); larger batches keep at least one workgroup per CU instead of 128
+                    // workgroups of 8 images (c5: conv2 / conv1 weight gradients 74 / 66 us on half the chip)
+                    if (wide) G = (P.Bb + 127) / 128;
+#if !defined(ISDQN_WGRAD_G128)
+                    if (wide && G > 2) G = std::max(2, (P.Bb + 255) / 256);
+#endif
                     if (G < 1) G = 1;
                     l.wgi_ntw = ntw;
                     l.wgi_G = G;
