@@ -127,7 +127,20 @@ __global__ __launch_bounds__(GEMM_THREADS * 2, 1) void conv_fwd_s8_pair_kernel(c
 
     auto do_image = [&](auto it_c) {
         constexpr int it = decltype(it_c)::value;
-        const int j = 2 * (int)blockIdx.x + it;
+        // Which two images: both on the XCD that PRODUCED them.  The first layer's workgroups for image i run on XCD i mod 8
+        // (xcd_image_tile), this kernel's workgroup b on XCD b mod 8 (round-robin dispatch), and the next layer's workgroup for
+        // image i on XCD i mod 8 again: with images 16 k + x and 16 k + 8 + x (x = b mod 8, k = b / 8) a workgroup reads rows
+        // that are still in its own XCD's L2 and leaves its output where the next kernel looks for it, instead of 2 b and
+        // 2 b + 1, whose producers and consumers sit on other XCDs (the fill then waits for the Infinity Cache).  Speed only.
+#if defined(ISDQN_PAIR_PLAIN_ORDER)
+        const bool by_xcd = false;
+#else
+        const bool by_xcd = (p.n_img & 15) == 0;
+#endif
+        const int bx = (int)blockIdx.x;
+        const int j_first = by_xcd ? ((bx >> 3) << 4) + (bx & 7) : 2 * bx;
+        const int j_second = by_xcd ? j_first + 8 : j_first + 1;
+        const int j = it == 0 ? j_first : j_second;
         const int rot = (int)((unsigned)(j >> 3) % (unsigned)nsteps);  // conv_fwd_img_kernel: (blockIdx.x >> 3) % nsteps with blockIdx.x = j
         auto slice = [&](int s) {  // K step of this group's loop position s (s < NPOS wherever it is called)
             const int k = s * KG + kg + rot;
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(GEMM_THREADS * 2, 1) void conv_fwd_s8_pair_kernel(c
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (it == 0) {
-                if (s == NPOS - 3) request(j + 1);  // behind the last weight-slice wait: two positions, the exchange and the epilogue cover the trip
+                if (s == NPOS - 3) request(j_second);  // behind the last weight-slice wait: two positions, the exchange and the epilogue cover the trip
             }
             __syncthreads();
         }
