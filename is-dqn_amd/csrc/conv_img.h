@@ -805,7 +805,11 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = mt * 16 + grp * 4 + r;
+#if !defined(ISDQN_NO_STREAMING)
+                if (row < g.cout_p && col < g.K) __builtin_nontemporal_store(acc[mt][t][r] * p.scale, (ISDQN_GLOBAL float*)(slab + (int64_t)row * g.K + col));
+#else
                 if (row < g.cout_p && col < g.K) slab[(int64_t)row * g.K + col] = acc[mt][t][r] * p.scale;
+#endif
             }
         }
 }

@@ -519,6 +519,13 @@ __device__ __forceinline__ void mask8(bool ok, float (&v)[8]) {  // for data tha
 // address was selected between a kernel argument and the zero block (a generic pointer would become `flat_load`,
 // which counts on both wait counters and completes out of order, so every wait turns into vmcnt(0) lgkmcnt(0)).
 #define ISDQN_GLOBAL __attribute__((address_space(1)))
+// Streaming ("nontemporal") 16-byte accesses for the big cold streams of the step: the optimizer's moments and master weights
+// (96 MB read once + written once by the fused-Adam GEMM) and the weight-gradient slabs' stores.  They do not claim cache lines the
+// kernels running beside them re-read: c2 +2 - 4 %.  NOT for anything a later kernel finds in L2 / the Infinity Cache: streaming the
+// forward's activation reads, the weight-gradient fills, the slab reads or the small tensors' moments cost 0.5 - 1.5 %, frames and
+// pre-activations made no difference (profiles/round4/cache_policy_ab.txt).
+__device__ __forceinline__ f32x4 nt_load4(const float* p) { return __builtin_nontemporal_load((const ISDQN_GLOBAL f32x4*)p); }
+__device__ __forceinline__ void nt_store4(float* p, const f32x4& v) { __builtin_nontemporal_store(v, (ISDQN_GLOBAL f32x4*)p); }
 __device__ __forceinline__ void load8_aligned(const float* p, float (&v)[8]) {
     ISDQN_BOUNDS_CHECK(p, 32, 1);
     const ISDQN_GLOBAL f32x4* gp = (const ISDQN_GLOBAL f32x4*)p;

@@ -179,9 +179,17 @@ struct PlainGemm {
                 ISDQN_BOUNDS_CHECK(adam.m + off[it], 16, 10);
                 ISDQN_BOUNDS_CHECK(adam.v + off[it], 16, 10);
                 ISDQN_BOUNDS_CHECK(adam.p + off[it], 16, 10);
+#if !defined(ISDQN_NO_STREAMING)
+                // moments and master weights are read once and written once per step: streamed past the caches (nt), so that the
+                // 96 MB they move do not evict what the data-gradient chain beside this kernel re-reads
+                pm[it] = __builtin_nontemporal_load((const ISDQN_GLOBAL f32x4*)(adam.m + off[it]));
+                pv[it] = __builtin_nontemporal_load((const ISDQN_GLOBAL f32x4*)(adam.v + off[it]));
+                pp[it] = __builtin_nontemporal_load((const ISDQN_GLOBAL f32x4*)(adam.p + off[it]));
+#else
                 pm[it] = *(const ISDQN_GLOBAL f32x4*)(adam.m + off[it]);
                 pv[it] = *(const ISDQN_GLOBAL f32x4*)(adam.v + off[it]);
                 pp[it] = *(const ISDQN_GLOBAL f32x4*)(adam.p + off[it]);
+#endif
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -209,9 +217,15 @@ struct PlainGemm {
                 }
                 if (on[it] && adam.grad_out) *reinterpret_cast<float4*>(adam.grad_out + off[it]) = g;
                 if (on[it] && adam.update) {
+#if !defined(ISDQN_NO_STREAMING)
+                    __builtin_nontemporal_store(nm, (ISDQN_GLOBAL f32x4*)(adam.m + off[it]));
+                    __builtin_nontemporal_store(nv, (ISDQN_GLOBAL f32x4*)(adam.v + off[it]));
+                    __builtin_nontemporal_store(np, (ISDQN_GLOBAL f32x4*)(adam.p + off[it]));
+#else
                     *reinterpret_cast<f32x4*>(adam.m + off[it]) = nm;
                     *reinterpret_cast<f32x4*>(adam.v + off[it]) = nv;
                     *reinterpret_cast<f32x4*>(adam.p + off[it]) = np;
+#endif
                     s8_store_quad(adam.mirror, (int)off[it], np[0], np[1], np[2], np[3]);  // (tensor sizes < 2^31)
                 }
             }
