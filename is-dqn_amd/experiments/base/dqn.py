@@ -29,6 +29,12 @@ def _gather_epoch_metrics(metrics: np.ndarray):
 def train(key, p: dict, agent, env, rb):
     """``key``: a numpy Generator (the reference threads a jax PRNGKey through the loop, dqn.py:34)."""
     rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+    # This loop owns the agent: every parameter write it causes goes through the agent's own methods (learn steps, head shifts,
+    # imports), so it may declare the weight mirror trusted between calls -- the acting forward of every environment step then skips
+    # an 8 us rebuild (one-environment loop: 918 -> 979 gradient steps/s).  Anyone who writes the parameters behind the agent's back
+    # keeps the default (slimdqn/_engine.py: trust_mirror).
+    if hasattr(agent, "trust_mirror"):
+        agent.trust_mirror = True
     epsilon_schedule = linear_schedule(1.0, p["epsilon_end"], p["epsilon_duration"])
     n_training_steps = 0
     env.reset()

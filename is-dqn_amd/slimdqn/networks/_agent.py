@@ -79,6 +79,7 @@ class EngineAgent:
         self._seed = int(key) if not isinstance(key, torch.Generator) else int(key.initial_seed())
         self._engine = None
         self._graphed = None
+        self._trust_mirror = None  # None: the engine's default (_engine.py: rebuild in every call); see the property below
         self._ring = None  # device copy of the acting path's frame stack (see _obs_to_device)
         self._make_engine(batch_size, init=True)
 
@@ -100,10 +101,27 @@ class EngineAgent:
             eng.losses_accum.copy_(old.losses_accum)
         self._drop_graph()  # captured against the old engine's buffers
         self._engine = eng
+        if self._trust_mirror is not None:
+            eng.trust_mirror = self._trust_mirror
         self._ring = None
         self.params = DeviceParams(eng, eng.params)
         self.optimizer_state = {"count": eng.adam_count, "mu": eng.adam_m, "nu": eng.adam_v}
         self._engine_changed(old)
+
+    @property
+    def trust_mirror(self) -> bool:
+        """Whether the engine may skip the weight-mirror rebuild while its bookkeeping says nothing wrote the parameters (an owner's
+        declaration that every write goes through torch or the agent: _engine.py).  Setting it re-captures the update graph."""
+        return bool(self._engine.trust_mirror)
+
+    @trust_mirror.setter
+    def trust_mirror(self, value: bool) -> None:
+        value = bool(value)
+        if value != bool(self._engine.trust_mirror):
+            self._drop_graph()  # (the captured replay has the rebuild node or not)
+            self._ring = None   # (and so have the acting graphs)
+        self._trust_mirror = value
+        self._engine.trust_mirror = value
 
     def _engine_changed(self, old) -> None:
         """Hook: a new engine replaced ``old`` (subclasses re-home extra device state)."""
