@@ -855,7 +855,7 @@ struct ConvDgradImgParams {
     FastDiv d_chunk, d_Wd, d_T;  // fill index math (chunks per pixel, padded width) and taps per axis of a class
     long long* stamps;           // profiling only (isdqn_debug_set_stamps), as in ConvImgParams
     int dz_plane;
-    int tiles_per_img;   // sum over classes of ceil(class pixels / 128)
+    int tiles_per_img;   // sum over classes of ceil(class pixels / tile pixels), tile = 64 * NT
     int cls_tile_start[5];
     PixelOrder cls_order[4];  // per class: position inside the class -> (row, column) of the class grid (8-wide strips)
     int n_classes;
@@ -863,10 +863,11 @@ struct ConvDgradImgParams {
 
 // (second launch-bound: two waves per SIMD, i.e. at most 256 registers -- the kernel sits right at that edge and two
 // workgroups per CU, its own or a weight-gradient one, are worth more than the last two registers)
-template <int MT, int PASSES>
+// NT = 16-pixel column tiles per wave: a workgroup covers 64 * NT pixels of a class.  NT = 1 halves the tile so that a batch
+// whose images would otherwise leave one workgroup (four waves) per CU launches two per image (net_plan.h: dgi_tile_pix).
+template <int MT, int PASSES, int NT = 2>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const ConvDgradImgParams p) {
     ISDQN_EMPTY_KERNEL_RETURN
-    constexpr int NT = 2;
     constexpr int BM = MT * 16;
     constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
     constexpr int B_PLANES = PASSES >= 3 ? 2 : 1;
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     xcd_image_tile((int)blockIdx.x, p.n_img, p.tiles_per_img, j, tl);
     int cls = 0;
     while (cls + 1 < p.n_classes && tl >= p.cls_tile_start[cls + 1]) ++cls;
-    const int q0 = (tl - p.cls_tile_start[cls]) * 128;  // first class-local pixel of this tile
+    const int q0 = (tl - p.cls_tile_start[cls]) * (64 * NT);  // first class-local pixel of this tile
     const int smask = g.stride - 1;  // (stride is a power of two: shifts and masks instead of divisions)
     const int cy = cls >> g.stride_sh, cx = cls & smask;
     const int Ha = (g.hin - cy + g.stride - 1) >> g.stride_sh, Wb = (g.win - cx + g.stride - 1) >> g.stride_sh;
@@ -983,7 +984,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     bool pix_ok[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        int q = q0 + wave * 32 + nt * 16 + column_slot(lane & 15);
+        int q = q0 + wave * (16 * NT) + nt * 16 + column_slot(lane & 15);
         pix_ok[nt] = q < n_cls_pix;
         q = pix_ok[nt] ? q : n_cls_pix - 1;
         int a, b;
@@ -1066,8 +1067,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
     ISDQN_STAMP(2);
     read_frags(0, slice(0), fr[0]);
     __syncthreads();  // every wave has read stage 0 before step 0 overwrites it with slice 2
-    // hand-interleaved K step for the 64-channel layer (24 MFMAs per step), as in conv_fwd_img_kernel
-    constexpr bool INTERLEAVED = PASSES == 3 && MT == 4 && NT == 2 && A_PER == 1 && GA::CHUNKS == GEMM_THREADS;
+    // hand-interleaved K step for the 64-channel layer (12 * NT MFMAs per step), as in conv_fwd_img_kernel
+    constexpr bool INTERLEAVED = PASSES == 3 && MT == 4 && A_PER == 1 && GA::CHUNKS == GEMM_THREADS;
     auto tap_offset_of = [&](int kk) {  // dz-image offset of this lane's 8-channel chunk of K step kk
         int kq = kk * GEMM_BK + grp * 8;
         kq = kq < k_last ? kq : k_last;
@@ -1091,21 +1092,32 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_dgrad_img_kernel(const C
                 __bf16* st_hi = a_stage + (s & 1) * A_STAGE + a_lds[0];
                 __bf16* st_lo = st_hi + GA::ELEMS;
                 bf16x8 c_hi, c_lo;
+                constexpr int NM = 12 * NT;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int jm = 0; jm < 24; ++jm) {
-                    const int pass = jm >> 3, nt = (jm >> 2) & 1, mt = jm & 3;
+                for (int jm = 0; jm < NM; ++jm) {
+                    const int pass = jm / (4 * NT), nt = (jm >> 2) % NT, mt = jm & 3;
                     mfma_acc(acc[mt][nt], pass == 1 ? fc.a_lo[mt] : fc.a_hi[mt], pass == 0 ? fc.b_lo[nt] : fc.b_hi[nt]);
                     if (jm < 4) fn.a_hi[jm] = read_frag<true, GA::PITCH>(na_hi, jm * 16, lane);
                     else if (jm < 8) fn.a_lo[jm - 4] = read_frag<true, GA::PITCH>(na_lo, (jm - 4) * 16, lane);
-                    else if (jm < 10) fn.b_hi[jm - 8] = *reinterpret_cast<const bf16x8*>(img + b_org[jm - 8] + tap_off);
-                    else if (jm < 12) fn.b_lo[jm - 10] = *reinterpret_cast<const bf16x8*>(img + b_org[jm - 10] + tap_off + p.dz_plane);
-                    else if (jm == 12) s8_unpack(sa[slot][0], c_hi, c_lo);  // S8 mirror: no conversion
-                    else if (jm < 16) {
-                    } else if (jm == 16) *reinterpret_cast<bf16x8*>(st_lo) = c_lo;
-                    else if (jm == 17) *reinterpret_cast<bf16x8*>(st_hi) = c_hi;
-                    else if (jm == 18) fetch(slot, slice(s + 2 + PF) * GEMM_BK);
-                    else if (jm == 19) tap_next = tap_offset_of(slice(s + 2));
+                    else if (jm < 8 + NT) fn.b_hi[jm - 8] = *reinterpret_cast<const bf16x8*>(img + b_org[jm - 8] + tap_off);
+                    else if (jm < 8 + 2 * NT) fn.b_lo[jm - 8 - NT] = *reinterpret_cast<const bf16x8*>(img + b_org[jm - 8 - NT] + tap_off + p.dz_plane);
+                    else if constexpr (NT == 2) {
+                        if (jm == 12) s8_unpack(sa[slot][0], c_hi, c_lo);  // S8 mirror: no conversion
+                        else if (jm == 16) *reinterpret_cast<bf16x8*>(st_lo) = c_lo;
+                        else if (jm == 17) *reinterpret_cast<bf16x8*>(st_hi) = c_hi;
+                        else if (jm == 18) fetch(slot, slice(s + 2 + PF) * GEMM_BK);
+                        else if (jm == 19) tap_next = tap_offset_of(slice(s + 2));
+                    } else {
+                        if (jm == 10) {
+                            s8_unpack(sa[slot][0], c_hi, c_lo);
+                            *reinterpret_cast<bf16x8*>(st_lo) = c_lo;
+                            *reinterpret_cast<bf16x8*>(st_hi) = c_hi;
+                        } else if (jm == 11) {
+                            fetch(slot, slice(s + 2 + PF) * GEMM_BK);
+                            tap_next = tap_offset_of(slice(s + 2));
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __syncthreads();
@@ -1289,16 +1301,16 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceJobs jobs)
     }
 }
 
-template <int MT, int PASSES>
+template <int MT, int PASSES, int NT = 2>
 static int launch_conv_dgrad_img(const ConvDgradImgParams& p, hipStream_t st) {
     constexpr int A_PLANES = PASSES >= 2 ? 2 : 1;
     constexpr int B_PLANES = PASSES >= 3 ? 2 : 1;
     using GA = TileGeom<MT * 16, true>;
     const int lds = (2 * A_PLANES * GA::ELEMS + B_PLANES * p.dz_plane) * 2;
     static LdsConfigured configured;
-    if (int rc = ensure_dynamic_lds(&conv_dgrad_img_kernel<MT, PASSES>, lds, configured)) return rc;
-    ISDQN_REPORT_OCCUPANCY((&conv_dgrad_img_kernel<MT, PASSES>), GEMM_THREADS, lds, p.n_img * p.tiles_per_img);
-    hipLaunchKernelGGL((conv_dgrad_img_kernel<MT, PASSES>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS), lds, st, p);
+    if (int rc = ensure_dynamic_lds(&conv_dgrad_img_kernel<MT, PASSES, NT>, lds, configured)) return rc;
+    ISDQN_REPORT_OCCUPANCY((&conv_dgrad_img_kernel<MT, PASSES, NT>), GEMM_THREADS, lds, p.n_img * p.tiles_per_img);
+    hipLaunchKernelGGL((conv_dgrad_img_kernel<MT, PASSES, NT>), dim3(p.n_img * p.tiles_per_img), dim3(GEMM_THREADS), lds, st, p);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
 }

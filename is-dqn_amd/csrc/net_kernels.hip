@@ -1616,7 +1616,7 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
         int Ha = (l.hin - cy + l.stride - 1) / l.stride, Wb = (l.win - cx + l.stride - 1) / l.stride;
         dp.cls_tile_start[c] = acc;
         dp.cls_order[c] = PixelOrder(Ha, Wb, Ha * Wb <= 128);  // (a class of several tiles keeps row-major tiles)
-        acc += ceil_div(Ha * Wb, 128);
+        acc += ceil_div(Ha * Wb, l.dgi_tile_pix);
     }
     dp.cls_tile_start[dp.n_classes] = acc;
     dp.tiles_per_img = acc;
@@ -1625,6 +1625,13 @@ static int conv_dgrad_img(const Layer& l, const Layer& below, bool x3, const flo
     const int lds = (2 * (passes >= 2 ? 2 : 1) * 32 * (mt * 16 + 16) + (passes >= 3 ? 2 : 1) * dp.dz_plane) * 2;  // TileGeom<.., true>
     if (lds > 150 * 1024) return ISDQN_OK;
     int rc;
+    ISDQN_REQUIRE(acc == l.dgi_tiles, ISDQN_ERR_ARG, "data-gradient tiling differs from the plan's");
+#if ISDQN_DGRAD_TILE64_BELOW > 0
+    if (l.dgi_tile_pix == 64) {
+        if (passes == 3) rc = mt == 2 ? launch_conv_dgrad_img<2, 3, 1>(dp, st) : launch_conv_dgrad_img<4, 3, 1>(dp, st);
+        else rc = mt == 2 ? launch_conv_dgrad_img<2, 1, 1>(dp, st) : launch_conv_dgrad_img<4, 1, 1>(dp, st);
+    } else
+#endif
     if (passes == 3) rc = mt == 2 ? launch_conv_dgrad_img<2, 3>(dp, st) : launch_conv_dgrad_img<4, 3>(dp, st);
     else rc = mt == 2 ? launch_conv_dgrad_img<2, 1>(dp, st) : launch_conv_dgrad_img<4, 1>(dp, st);
     if (rc) return rc;
@@ -2060,11 +2067,25 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                                                      head.gw_slabs, head.w_size, s2);  // dL/dq fp32, hidden activations S8
     };
     std::function<int()> deferred;  // side-stream launches of the layer above, held back until this layer's data gradient is enqueued
-#if defined(ISDQN_FORK_LATE)
-    const bool fork_late = ss != nullptr;
-#else
-    const bool fork_late = false;
+    // Which queue the replayed graph gives a kernel: a node's FIRST-created successor stays on its queue, the others move to
+    // another one and start ~12 us late.  Round 4's order (c2 +1.2 %, c3 +7.5 %; -DISDQN_FORK_LATE_MAX_B=0 keeps round 3's):
+    //   * the data-gradient chain is created first behind every fork, so it stays on the capturing queue all the way;
+    //   * the two small kernels that only need the head chain's outputs (loss sums, head weight gradient) become successors of the
+    //     HEAD CHAIN on the side stream -- created behind the dense data gradient, which therefore stays the head chain's first
+    //     successor -- and run under the dense data gradient; the new queue's late start is hidden there, and it is what lets the
+    //     first convolution data gradient become resident before the fused-Adam GEMM's 968 workgroups ask for the CUs.
+    // Large batches keep round 3's order: at B = 1024 every kernel is several rounds of workgroups, which queue gets the CUs first
+    // no longer matters and the new order measured 0.6 % slower (profiles/round4/ab_fork_c5.txt; ab_thresholds.txt: +2.0 % at
+    // B = 32, +1.7 % at 128, +1.5 % at 512, +2.0 % at 768).
+    hipEvent_t head_event = nullptr;
+#if !defined(ISDQN_FORK_LATE_MAX_B)
+#define ISDQN_FORK_LATE_MAX_B 768
 #endif
+    const bool fork_late = ss != nullptr && P.L[0].kind != 2 && B <= ISDQN_FORK_LATE_MAX_B;
+    if (fork_late && head_deferred) {
+        head_event = ss->ev[ss->next.fetch_add(1, std::memory_order_relaxed) % (unsigned)ss->n_ev];
+        ISDQN_HIP_CHECK(hipEventRecord(head_event, st));
+    }
     for (int i = P.n_layers - 1; i >= 0; --i) {
         const Layer& l = P.L[i];
         const float* act_in = i > 0 ? ws + P.L[i - 1].act_off : nullptr;
@@ -2202,6 +2223,11 @@ static int learn_or_loss(const isdqn_net_config* cfg, float* params, float* adam
                 // start ~12 us late.  The successor that matters is the next data gradient: record the fork here,
                 // but create the side stream's kernels (loss_finalize, head weight gradient, this layer's weight gradient) only
                 // after that data gradient has been enqueued on the caller's stream.
+                if (head_event != nullptr && head_deferred) {  // (the dense data gradient is enqueued: the head chain keeps it as first successor)
+                    ISDQN_HIP_CHECK(hipStreamWaitEvent(lws, head_event, 0));
+                    rc = run_head_deferred(lws);
+                    if (rc) return rc;
+                }
                 defer_event = ss->ev[ss->next.fetch_add(1, std::memory_order_relaxed) % (unsigned)ss->n_ev];
                 ISDQN_HIP_CHECK(hipEventRecord(defer_event, st));
                 defer_side = true;

@@ -40,6 +40,7 @@ struct Layer {
     int wgi_ntw, wgi_G, wgi_groups;
     // conv (layer >= 1): image-resident data gradient with the LayerNorm backward of the layer below fused in
     int dgi_tiles;       // workgroups per image (0 = generic engine + separate ln_bwd)
+    int dgi_tile_pix;    // pixels of a class per workgroup: 128, or 64 when 128 would leave fewer than two workgroups per CU
     int64_t red_off;     // hidden layers: reduced (dgamma, dbeta, dbias) row [3][out_p]
     int part_rows;       // rows of the partial-sum region
     char name[16];
@@ -344,13 +345,25 @@ static inline int build_plan_uncached(const isdqn_net_config* cfg, Plan& P) {
         l.act_off = l.z_off = l.dz_off = l.part_off = -1;
         l.dgi_tiles = 0;
         if (l.kind == 0 && i > 0 && l.ksz % l.stride == 0 && l.cout_p <= 64 && l.cin_p <= 64) {
-            int tiles = 0;
-            for (int c = 0; c < l.stride * l.stride; ++c) {
-                int cy = c / l.stride, cx = c % l.stride;
-                int Ha = (l.hin - cy + l.stride - 1) / l.stride, Wb = (l.win - cx + l.stride - 1) / l.stride;
-                tiles += ceil_div(Ha * Wb, 128);
-            }
-            l.dgi_tiles = tiles;
+            auto tiles_of = [&](int tile_pix) {
+                int tiles = 0;
+                for (int c = 0; c < l.stride * l.stride; ++c) {
+                    int cy = c / l.stride, cx = c % l.stride;
+                    int Ha = (l.hin - cy + l.stride - 1) / l.stride, Wb = (l.win - cx + l.stride - 1) / l.stride;
+                    tiles += ceil_div(Ha * Wb, tile_pix);
+                }
+                return tiles;
+            };
+            // One four-wave workgroup per CU cannot hide its own latencies (round 4, stamps_dgrad.txt: a K step of 384 MFMA
+            // cycles takes 1 080), and half tiles make the conv2 data gradient of c2 7 us shorter (26.2 -> 18.9) -- but they fill
+            // the image and read the weight fragments twice, and in the step that CU time is taken from the kernels of the other
+            // queue (ab_tile64_c2.txt: the step is 3.7 % SLOWER at B = 256; at B = 32, where the chip is
+            // mostly empty either way, +0.2 %: noise).  Off in the product; -DISDQN_DGRAD_TILE64_BELOW=<workgroups> builds them.
+#if !defined(ISDQN_DGRAD_TILE64_BELOW)
+#define ISDQN_DGRAD_TILE64_BELOW 0
+#endif
+            l.dgi_tile_pix = P.Bb * tiles_of(128) < ISDQN_DGRAD_TILE64_BELOW ? 64 : 128;
+            l.dgi_tiles = tiles_of(l.dgi_tile_pix);
         }
         if (!l.is_head) {
             l.act_off = region(std::string("act/") + l.name, (int64_t)P.N2 * l.out_elems_p);
