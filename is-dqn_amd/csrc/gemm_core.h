@@ -526,6 +526,22 @@ __device__ __forceinline__ void mask8(bool ok, float (&v)[8]) {  // for data tha
 // pre-activations made no difference (profiles/round4/cache_policy_ab.txt).
 __device__ __forceinline__ f32x4 nt_load4(const float* p) { return __builtin_nontemporal_load((const ISDQN_GLOBAL f32x4*)p); }
 __device__ __forceinline__ void nt_store4(float* p, const f32x4& v) { __builtin_nontemporal_store(v, (ISDQN_GLOBAL f32x4*)p); }
+// optax.adam on one element (isdqn.py:46, 85-86; optax scale_by_adam + scale(-lr)):  m, v updated in place, returns the new parameter.
+// `inv_c1` / `inv_c2` = 1 / (1 - b^t), one IEEE division per thread; the square root and the reciprocal of (sqrt(v_hat) + eps) are the
+// hardware's 1-ulp v_sqrt_f32 / v_rcp_f32: the three IEEE divisions and the refined square root per element they replace were 66 vector
+// instructions per element in the fused-Adam GEMM's epilogue (two thirds of that kernel's instruction stream).  The update differs
+// from the all-IEEE form by < 3e-7 of itself, i.e. < 2e-11 absolute at lr = 6.25e-5 -- below one ulp of any parameter above 2e-4.
+__device__ __forceinline__ float adam_element(float& m, float& v, float p, float g, float b1, float b2, float lr, float eps, float inv_c1,
+                                              float inv_c2) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+#if defined(ISDQN_ADAM_IEEE)
+    return p - lr * ((m * inv_c1) / (sqrtf(v * inv_c2) + eps));
+#else
+    const float den = __builtin_amdgcn_sqrtf(v * inv_c2) + eps;
+    return p - lr * ((m * inv_c1) * __builtin_amdgcn_rcpf(den));
+#endif
+}
 __device__ __forceinline__ void load8_aligned(const float* p, float (&v)[8]) {
     ISDQN_BOUNDS_CHECK(p, 32, 1);
     const ISDQN_GLOBAL f32x4* gp = (const ISDQN_GLOBAL f32x4*)p;

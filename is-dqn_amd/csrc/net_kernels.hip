@@ -1041,14 +1041,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* _
     if (grad_out != nullptr) *reinterpret_cast<float4*>(grad_out + o) = g;
     if (!update) return;  // gradient only (isdqn_net_grad_on_batch)
     float* gp = &g.x; float* mp = &pm.x; float* vp = &pv.x; float* xp = &pp.x;
+    const float inv_c1 = 1.f / c1, inv_c2 = 1.f / c2;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float mm = b1 * mp[r] + (1.f - b1) * gp[r];
-        float vv = b2 * vp[r] + (1.f - b2) * gp[r] * gp[r];
-        mp[r] = mm;
-        vp[r] = vv;
-        xp[r] = xp[r] - lr * ((mm / c1) / (sqrtf(vv / c2) + eps));
-    }
+    for (int r = 0; r < 4; ++r) xp[r] = adam_element(mp[r], vp[r], xp[r], gp[r], b1, b2, lr, eps, inv_c1, inv_c2);
     *reinterpret_cast<float4*>(m + o) = pm;
     *reinterpret_cast<float4*>(v + o) = pv;
     *reinterpret_cast<float4*>(p + o) = pp;

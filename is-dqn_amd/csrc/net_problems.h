@@ -199,7 +199,7 @@ struct PlainGemm {
                     for (int r = 0; r < 4; ++r)
                         tg[(lm + mt * 16 + (lane >> 4) * 4 + r) * LD + ln + nt * 16 + (lane & 15)] = acc[mt][nt][r];
             __syncthreads();
-            const float c1 = adam.consts[0], c2 = adam.consts[1];
+            const float inv_c1 = 1.f / adam.consts[0], inv_c2 = 1.f / adam.consts[1];
 #pragma unroll
             for (int it = 0; it < N_IT; ++it) {
                 const int i = tid + it * GEMM_THREADS;
@@ -209,11 +209,10 @@ struct PlainGemm {
                 f32x4 nm, nv, np;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float mm = adam.b1 * pm[it][r] + (1.f - adam.b1) * gp[r];
-                    const float vv = adam.b2 * pv[it][r] + (1.f - adam.b2) * gp[r] * gp[r];
+                    float mm = pm[it][r], vv = pv[it][r];
+                    np[r] = adam_element(mm, vv, pp[it][r], gp[r], adam.b1, adam.b2, adam.lr, adam.eps, inv_c1, inv_c2);
                     nm[r] = mm;
                     nv[r] = vv;
-                    np[r] = pp[it][r] - adam.lr * ((mm / c1) / (sqrtf(vv / c2) + adam.eps));
                 }
                 if (on[it] && adam.grad_out) *reinterpret_cast<float4*>(adam.grad_out + off[it]) = g;
                 if (on[it] && adam.update) {
