@@ -25,6 +25,7 @@ reported as `settle_steps`, which take a fresh process to its steady state; a se
 replays with HIP events for median / p10 / p90.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -105,7 +106,7 @@ def measured_traffic(workload, precision):
 class Replica:
     """One independent (seed) replica of the training state on one GPU."""
 
-    def __init__(self, workload, capacity, precision, seed, device):
+    def __init__(self, workload, capacity, precision, seed, device, trust_mirror=True):
         import torch
         from slimdqn._engine import QNetEngine
         from slimdqn.sample_collection.replay_buffer import ReplayBuffer
@@ -127,6 +128,10 @@ class Replica:
                               gamma_n=0.99 ** w["n"], learning_rate=6.25e-5, adam_eps=1.5e-4, precision=precision,
                               device=device)
         self.eng.init_params(seed)
+        # The bench owns this engine the way the trainer owns its agent (experiments/base/dqn.py: train sets agent.trust_mirror): every
+        # parameter write of the run goes through the engine, so a replay does not re-derive the bf16 weight mirror at its head
+        # (8 us per replay; --rebuild-mirror keeps the engine's default, which assumes nothing about its caller).
+        self.eng.trust_mirror = trust_mirror
         torch.cuda.synchronize()
         self.graphed = None
 
@@ -289,12 +294,12 @@ def partitioned_streams(R: int, device):
     return out
 
 
-def steps_per_graph(steps: int, limit: int) -> int:
+def steps_per_graph(steps: int, limit: int, min_replays: int = 4) -> int:
     """Largest S <= limit dividing the timed step count (a graph replays S steps at a time: the timed region is EXACTLY `steps`) that
     leaves at least four replays in it -- launching a replay overlaps the previous one's execution; ONE 20-step replay measured 3 460 -
     3 830 steps/s where four 5-step replays give 3 790 - 3 980.  The untimed phase in front runs whole replays too: at least the
     requested warm-up, the surplus is reported with `settle_steps`."""
-    limit = max(1, min(limit, steps // 4))
+    limit = max(1, min(limit, steps // max(1, min_replays)))
     return max(d for d in range(1, limit + 1) if steps % d == 0)
 
 
@@ -304,7 +309,7 @@ def main():
     # defaults: ~1.2 s of timed work (300-step runs scatter by +-15 %) behind ~1.2 s of warm-up
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=4000)
-    ap.add_argument("--settle", type=int, default=-1, help="untimed steps in front of the warm-up (default: up to 2000 so that warm-up + settle >= 2000)")
+    ap.add_argument("--settle", type=int, default=-1, help="untimed steps in front of the warm-up (default: so that warm-up + settle >= 4000, one second)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--K", type=int, default=0, help="override the number of Bellman iterations of the workload (the reference's "
                     "timing sweep launch_job/atari/launch_time.sh:13-27 runs K in 1, 4, 9, 49)")
@@ -312,6 +317,9 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--capacity", type=int, default=1_000_000)
     ap.add_argument("--graph", type=int, default=32, help="most steps captured per hipGraph (0 = eager launches)")
+    ap.add_argument("--rebuild-mirror", action="store_true", help="rebuild the bf16 weight mirror at the head of every replay (the engine's "
+                    "default for callers it knows nothing about) instead of declaring, as the trainer does, that all parameter writes are the engine's own")
+    ap.add_argument("--min-replays", type=int, default=4, help="fewest graph replays the timed region is cut into")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="wall-clock cap of EACH timed leg of the CPU baseline (50 steps each otherwise)")
     ap.add_argument("--cpu-capacity", type=int, default=1_000_000)
@@ -353,11 +361,12 @@ def main():
     w = WORKLOADS[args.workload]
 
     R = max(1, args.replicas_per_gpu)
-    reps = [Replica(args.workload, args.capacity, args.precision, seed=rank * R + r, device=device) for r in range(R)]
+    reps = [Replica(args.workload, args.capacity, args.precision, seed=rank * R + r, device=device, trust_mirror=not args.rebuild_mirror)
+            for r in range(R)]
     rep = reps[0]
     S = 1
     if args.graph > 0:
-        S = steps_per_graph(args.steps, args.graph)
+        S = steps_per_graph(args.steps, args.graph, args.min_replays)
         try:
             for x in reps:
                 x.enable_graph(S)
@@ -375,12 +384,21 @@ def main():
             for x, st in zip(reps, streams):
                 with torch.cuda.stream(st):
                     x.graphed.run() if x.graphed is not None else x.step()
-    settle = args.settle if args.settle >= 0 else max(0, 2000 - args.warmup)
+    settle = args.settle if args.settle >= 0 else max(0, 4000 - args.warmup)
     untimed = (settle + args.warmup + S - 1) // S * S  # whole replays: >= settle + warm-up
-    settle = untimed - args.warmup
     for _ in range(untimed // S):
         one()
     torch.cuda.synchronize()
+    # One more untimed replay, drained on its own: the first launch behind hundreds of back-to-back replays pays for the runtime
+    # reclaiming their submission resources (410 - 510 us on the host against 250 for the following ones; 290 behind a drained
+    # replay) -- inside a 20-step timed region that is 4 % and most of its scatter (profiles/round4/driver_form_host.txt, _host2.txt).
+    one()
+    untimed += S
+    settle = untimed - args.warmup
+    torch.cuda.synchronize()
+    # Nothing slow between that synchronisation and the timed region: 20 ms of idle GPU cost the next 5 ms 10 % of their clock (a
+    # gc.collect() here measured 3 650 steps/s against 4 150; driver_form_host.txt "20 ms host spin", driver_form_variants.txt).
+    gc.disable()  # (no collector pause inside a 5 ms region; re-enabled behind it)
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
@@ -399,6 +417,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     rep.rb._sampling_distribution._sum_tree.check_status() if w["prioritized"] else None
 
     elapsed_max = max_over_ranks(elapsed, device)
@@ -448,7 +467,8 @@ def main():
             "dtype": "bf16x3 (split-bf16 MFMA operands hi+lo, fp32 accumulate)" if args.precision == "bf16x3" else "bf16 (single pass, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": w["desc"], "replay_capacity": args.capacity, "precision": args.precision,
-                       "launch": f"hipGraph x{S} steps" if rep.graphed is not None else "eager", "replicas": world * R, "replicas_per_gpu": R, "cu_partition": bool(args.cu_partition and R > 1), "parallelism": f"independent-seed replicas x{world * R}"},
+                       "launch": f"hipGraph x{S} steps" if rep.graphed is not None else "eager",
+                       "weight_mirror": "rebuilt at the head of every replay" if args.rebuild_mirror else "owned by the caller (trainer's setting)", "replicas": world * R, "replicas_per_gpu": R, "cu_partition": bool(args.cu_partition and R > 1), "parallelism": f"independent-seed replicas x{world * R}"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,

@@ -3,7 +3,7 @@
 # kernel-trace / PMC profiles of the three graphed workloads.  Results under gpurun_out/final4/ (copied into profiles/round4/).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final4; mkdir -p $out
-export ISDQN_BUILD_TAG="round 4 HEAD (fused-Adam GEMM streams p / m / v nontemporally, weight-gradient slab stores likewise; mirror rebuilt at the head of every replay; 13x13 dz image in the conv2 data gradient; weight-gradient groups follow the batch; XCD-affine image order in the conv1 pair kernel)"
+export ISDQN_BUILD_TAG="round 4 HEAD (head kernels on the side queue under the dense data gradient, data-gradient chain first behind every fork; hardware rcp / sqrt in the Adam element; fused-Adam GEMM streams p / m / v nontemporally, weight-gradient slab stores likewise; mirror rebuilt at the head of every replay; 13x13 dz image in the conv2 data gradient; weight-gradient groups follow the batch; XCD-affine image order in the conv1 pair kernel)"
 timeout -k 10 1000 python -m pytest tests -q -m gpu -x > $out/gputests_full_suite.log 2>&1 || { tail -20 $out/gputests_full_suite.log; exit 1; }
 tail -2 $out/gputests_full_suite.log
 timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_c2_driver_form.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
