@@ -106,7 +106,7 @@ def measured_traffic(workload, precision):
 class Replica:
     """One independent (seed) replica of the training state on one GPU."""
 
-    def __init__(self, workload, capacity, precision, seed, device, trust_mirror=True):
+    def __init__(self, workload, capacity, precision, seed, device, trust_mirror=False):
         import torch
         from slimdqn._engine import QNetEngine
         from slimdqn.sample_collection.replay_buffer import ReplayBuffer
@@ -128,9 +128,10 @@ class Replica:
                               gamma_n=0.99 ** w["n"], learning_rate=6.25e-5, adam_eps=1.5e-4, precision=precision,
                               device=device)
         self.eng.init_params(seed)
-        # The bench owns this engine the way the trainer owns its agent (experiments/base/dqn.py: train sets agent.trust_mirror): every
-        # parameter write of the run goes through the engine, so a replay does not re-derive the bf16 weight mirror at its head
-        # (8 us per replay; --rebuild-mirror keeps the engine's default, which assumes nothing about its caller).
+        # `trust_mirror`: main() owns its engines the way the trainer owns its agent (experiments/base/dqn.py: train sets
+        # agent.trust_mirror) -- every parameter write of the run goes through the engine, so a replay does not re-derive the bf16
+        # weight mirror at its head (8 us per replay).  --rebuild-mirror, and every other user of this class (the GPU tests), keep the
+        # engine's default, which assumes nothing about its caller.
         self.eng.trust_mirror = trust_mirror
         torch.cuda.synchronize()
         self.graphed = None

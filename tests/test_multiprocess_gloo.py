@@ -89,6 +89,7 @@ def test_bench_steps_per_graph_divides_the_timed_steps():
     assert bench.steps_per_graph(20, 4) == 4
     assert bench.steps_per_graph(4000, 32) == 32
     assert bench.steps_per_graph(7, 8) == 1 and bench.steps_per_graph(24, 8) == 6 and bench.steps_per_graph(3, 8) == 1
+    assert bench.steps_per_graph(20, 32, min_replays=2) == 10 and bench.steps_per_graph(20, 32, min_replays=1) == 20
 
 
 def test_launcher_refuses_incomplete_arguments_before_starting_anything():
