@@ -161,6 +161,63 @@ __device__ __forceinline__ void fill_image_s8(__bf16* img, int plane_elems, cons
     }
 }
 
+// The same copy in two halves for a workgroup that stages one image after another: `request` issues the loads of ALL chunks of
+// this thread (at most N; the caller checks that the image fits N * NTHR chunks) and touches none of them, `commit` converts and
+// writes them to LDS.  Between the two the registers travel under whatever the workgroup computes on the image it already holds
+// (barriers wait for LDS traffic only, and nothing else in those kernels' K steps loads from global memory: the requests stay
+// the newest loads until the commit).
+template <int N>
+struct ImagePrefetch {
+    float v[N][8];
+    int dst[N];
+};
+template <int NTHR, int N>
+__device__ __forceinline__ void request_image_s8(ImagePrefetch<N>& r, const float* src, int H, int W, int C, int y0, int x0, int Rl, int Wl,
+                                                 int PP, int tid, const FastDiv& d_cpp, const FastDiv& d_Wl) {
+    const int cpp = C >> 3, n_chunks = Rl * Wl * cpp;
+    uint32_t pix_u, cc_u, lr_u, xl_u;
+    d_cpp.divmod((uint32_t)tid, pix_u, cc_u);
+    d_Wl.divmod(pix_u, lr_u, xl_u);
+    int cc = (int)cc_u, lr = (int)lr_u, xl = (int)xl_u, pix = (int)pix_u;
+    uint32_t dpix_u, dcc_u, dpy_u, dpx_u;
+    d_cpp.divmod((uint32_t)NTHR, dpix_u, dcc_u);
+    d_Wl.divmod(dpix_u, dpy_u, dpx_u);
+    const int dpix = (int)dpix_u, dcc = (int)dcc_u, dpy = (int)dpy_u, dpx = (int)dpx_u;
+    int c0 = tid;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const bool on = c0 < n_chunks;
+        const int iy = y0 + lr, ix = x0 + xl;
+        const bool ok = on && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        load8_aligned(ok ? src + ((iy * W + ix) * C + cc * 8) : zero_chunk(), r.v[u]);
+        r.dst[u] = on ? pix * PP + cc * 8 : -1;
+        c0 += NTHR;
+        cc += dcc;
+        const int carry_c = cc >= cpp ? 1 : 0;
+        cc -= carry_c ? cpp : 0;
+        pix += dpix + carry_c;
+        xl += dpx + carry_c;
+        lr += dpy;
+        const int carry_x = xl >= Wl ? 1 : 0;
+        xl -= carry_x ? Wl : 0;
+        lr += carry_x;
+    }
+}
+template <int PLANES, int N>
+__device__ __forceinline__ void commit_image_s8(__bf16* img, int plane_elems, const ImagePrefetch<N>& r) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        bf16x8 hi, lo;
+        if constexpr (PLANES >= 2) {
+            s8_unpack(r.v[u], hi, lo);
+            if (r.dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + plane_elems + r.dst[u]) = lo;
+        } else {
+            s8_unpack_hi(r.v[u], hi);
+        }
+        if (r.dst[u] >= 0) *reinterpret_cast<bf16x8*>(img + r.dst[u]) = hi;
+    }
+}
+
 // uint8 frames -> the planar bf16 LDS image img[c][lr][Wp] (zero border included), 8 columns per chunk.
 // Position-major: a thread owns (row, chunk-of-8-columns) positions and walks the `stack` planes of each, so the divisions,
 // the border tests and the in-frame offset are computed once per position instead of once per chunk -- with four workgroups
@@ -679,7 +736,12 @@ struct ConvWgradImgParams {
     int dz_plane;        // elements of one precision plane of the dz image
     FastDiv d_ncg;         // by n_col_groups
     FastDiv d_chunk, d_Wp, d_R, d_dzchunk, d_npixpad;  // fill index math (see ConvImgParams); d_npixpad: by npix_pad
+    int prefetch;          // the next image of the group is requested into registers under this image's K steps (set by the launcher)
+    long long* stamps;     // profiling only (isdqn_debug_set_stamps "wgrad:<layer>"), as in ConvImgParams
 };
+// chunks per thread the prefetching form holds (dz image / input image): the 64-channel layers of the headline network on 256 and
+// 512 threads (11 x 11 x 64 dz = 4 / 2; 13 x 13 x 64 input = 6, 24 x 24 x 32 input on 512 threads = 5)
+template <int WV> struct WgradPrefetch { static constexpr int DZ = 1024 / (64 * WV), IN = WV == 4 ? 6 : 5; };
 
 template <bool U8, int PASSES, int NTHR = GEMM_THREADS>
 __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, const ConvGeom& g, const FrameSrc& fs,
@@ -716,6 +778,16 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
     __bf16* img = dzi + A_PLANES * p.dz_plane;             // B_PLANES planes of the input image
     const ConvGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if defined(ISDQN_DEV)  // phase stamps of the first two images of the group: 0 start, 1 / 3 image staged, 2 / 4 its K steps done, 5 slab stored
+#define WG_STAMP(i)                                                                                   \
+    if (p.stamps != nullptr && threadIdx.x == 0) {                                                   \
+        p.stamps[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime();            \
+        if ((i) == 0) p.stamps[(int64_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    }
+#else
+#define WG_STAMP(i)
+#endif
+    WG_STAMP(0);
     uint32_t ig_u, cg_u;
     p.d_ncg.divmod(blockIdx.x, ig_u, cg_u);
     const int cg = (int)cg_u, ig = (int)ig_u;
@@ -745,14 +817,7 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
         for (int t = 0; t < NTW; ++t) mfma_init(acc[mt][t]);
 
     const int nsteps = p.npix_pad / GEMM_BK;
-    for (int j = j0; j < j1; ++j) {
-        __syncthreads();  // previous image fully consumed
-        // ---- dz image: [npix_pad][PA], rows >= npix are zero (one "row" of npix_pad pixels for the walker) ----
-        fill_image_s8<NTHR, A_PLANES, 8>(dzi, p.dz_plane, p.dz + (int64_t)j * g.npix * g.cout_p, 1, g.npix, g.cout_p, 0, 0, 1, p.npix_pad,
-                                         p.PA, tid, p.d_dzchunk, p.d_npixpad);
-        fill_input_image<U8, PASSES, NTHR>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, p.PPin, tid, p.d_chunk, p.d_Wp, p.d_R);
-        __syncthreads();
-
+    auto k_steps = [&]() {
         for (int ks = 0; ks < nsteps; ++ks) {
             // The two 4-row blocks of this lane's 8-pixel group.  The contraction order is free, so k row 8*grp + 4*h + q of
             // the step takes pixel tr_row(.) of its 32: the eight k rows one 32-lane group of a ds_read_b64_tr_b16 addresses
@@ -794,6 +859,43 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
                 }
             }
         }
+    };
+    bool staged = false;
+    if constexpr (!U8) {
+        if (p.prefetch) {  // (uniform) two or more images per group and both images fit the register budget
+            staged = true;
+            ImagePrefetch<WgradPrefetch<WV>::DZ> ra;
+            ImagePrefetch<WgradPrefetch<WV>::IN> rb;
+            auto request = [&](int j) {
+                request_image_s8<NTHR>(ra, p.dz + (int64_t)j * g.npix * g.cout_p, 1, g.npix, g.cout_p, 0, 0, 1, p.npix_pad, p.PA, tid,
+                                       p.d_dzchunk, p.d_npixpad);
+                request_image_s8<NTHR>(rb, p.in + (int64_t)j * g.hin * g.win * g.cin_p, g.hin, g.win, g.cin_p, -g.pad, -g.pad, p.R, p.Wp,
+                                       p.PPin, tid, p.d_chunk, p.d_Wp);
+            };
+            request(j0);
+            for (int j = j0; j < j1; ++j) {
+                __syncthreads();  // previous image fully consumed
+                commit_image_s8<A_PLANES>(dzi, p.dz_plane, ra);
+                commit_image_s8<B_PLANES>(img, p.in_plane, rb);
+                __syncthreads();
+                if (j == j0) { WG_STAMP(1); } else if (j == j0 + 1) { WG_STAMP(3); }
+                if (j + 1 < j1) request(j + 1);  // travels under this image's K steps
+                k_steps();
+                if (j == j0) { WG_STAMP(2); } else if (j == j0 + 1) { WG_STAMP(4); }
+            }
+        }
+    }
+    if (!staged)
+    for (int j = j0; j < j1; ++j) {
+        __syncthreads();  // previous image fully consumed
+        // ---- dz image: [npix_pad][PA], rows >= npix are zero (one "row" of npix_pad pixels for the walker) ----
+        fill_image_s8<NTHR, A_PLANES, 8>(dzi, p.dz_plane, p.dz + (int64_t)j * g.npix * g.cout_p, 1, g.npix, g.cout_p, 0, 0, 1, p.npix_pad,
+                                         p.PA, tid, p.d_dzchunk, p.d_npixpad);
+        fill_input_image<U8, PASSES, NTHR>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, p.PPin, tid, p.d_chunk, p.d_Wp, p.d_R);
+        __syncthreads();
+        if (j == j0) { WG_STAMP(1); } else if (j == j0 + 1) { WG_STAMP(3); }
+        k_steps();
+        if (j == j0) { WG_STAMP(2); } else if (j == j0 + 1) { WG_STAMP(4); }
     }
 
     float* slab = p.slabs + (int64_t)ig * g.cout_p * g.K;
@@ -812,6 +914,13 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
 #endif
             }
         }
+#if defined(ISDQN_DEV)
+    if (p.stamps != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0);
+        WG_STAMP(5);
+    }
+#endif
+#undef WG_STAMP
 }
 
 template <int MT, int NTW, int PASSES, bool U8, int WV = 4>
@@ -822,8 +931,15 @@ static int launch_conv_wgrad_img(const ConvWgradImgParams& p, int n_img_groups, 
     static LdsConfigured configured;
     if (int rc = ensure_dynamic_lds(&conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>, lds, configured)) return rc;
     ISDQN_REPORT_OCCUPANCY((&conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>), 64 * WV, lds, n_img_groups * p.n_col_groups);
+    ConvWgradImgParams q = p;
+    q.prefetch = 0;
+#if !defined(ISDQN_WGRAD_NO_PREFETCH)
+    if (!U8 && p.G >= 2 && p.npix_pad * (p.g.cout_p / 8) <= WgradPrefetch<WV>::DZ * 64 * WV &&
+        p.R * p.Wp * (p.g.cin_p / 8) <= WgradPrefetch<WV>::IN * 64 * WV)
+        q.prefetch = 1;
+#endif
     hipLaunchKernelGGL((conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>), dim3(n_img_groups * p.n_col_groups),
-                       dim3(64 * WV), lds, st, p);
+                       dim3(64 * WV), lds, st, q);
     ISDQN_HIP_CHECK(hipGetLastError());
     return ISDQN_OK;
 }

@@ -1528,6 +1528,11 @@ static int conv_wgrad_img(const Layer& l, bool x3, const NetInput& in, const flo
     wp.NC = 64 * l.wgi_ntw;
     wp.n_col_groups = l.K / wp.NC;
     wp.d_ncg = FastDiv((uint32_t)wp.n_col_groups);
+    {
+        char tag[32];
+        snprintf(tag, sizeof(tag), "wgrad:%s", l.name);
+        wp.stamps = stamps_for(tag);
+    }
     const int groups = ceil_div(n_img, l.wgi_G);
     *slabs_out = groups;
 #define WGI(MT_, NTW_, P_, U_) return launch_conv_wgrad_img<MT_, NTW_, P_, U_>(wp, groups, st)

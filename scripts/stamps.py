@@ -38,6 +38,8 @@ span_cyc = s[:, 5].max() - t0
 span_rt = (s[:, 7].max() - s[:, 7].min())  # start-to-last-start only; use as lower bound
 order = np.argsort(s[:, 0])
 names = ["fill(load+convert+write)", "weights0+sync", "K loop", "epilogue issue", "store drain"]
+if layer.startswith("wgrad:"):
+    names = ["image 0 staged (fetch + commit)", "K steps of image 0", "image 1 staged (commit)", "K steps of image 1", "slab stores drained"]
 if layer == "head_chain":
     names = ["operand requests + hidden rows -> LDS", "head GEMM", "q reduce + targets/TD", "data-gradient AXPY", "LayerNorm backward"]
 print("(layer may be e.g. Conv_1 for the forward kernel or dgrad:Conv_1 for the data-gradient kernel of that layer)")
