@@ -741,7 +741,8 @@ struct ConvWgradImgParams {
 };
 // chunks per thread the prefetching form holds (dz image / input image): the 64-channel layers of the headline network on 256 and
 // 512 threads (11 x 11 x 64 dz = 4 / 2; 13 x 13 x 64 input = 6, 24 x 24 x 32 input on 512 threads = 5)
-template <int WV> struct WgradPrefetch { static constexpr int DZ = 1024 / (64 * WV), IN = WV == 4 ? 6 : 5; };
+// (first layer, uint8 input: the 21 x 21 x 32 dz image = 7 chunks per thread of 256)
+template <int WV> struct WgradPrefetch { static constexpr int DZ = 1024 / (64 * WV), IN = WV == 4 ? 6 : 5, DZ_U8 = 1792 / (64 * WV); };
 
 template <bool U8, int PASSES, int NTHR = GEMM_THREADS>
 __device__ __forceinline__ void fill_input_image(__bf16* img, int plane_elems, const ConvGeom& g, const FrameSrc& fs,
@@ -889,9 +890,22 @@ __global__ __launch_bounds__(64 * WV) void conv_wgrad_img_kernel(const ConvWgrad
     for (int j = j0; j < j1; ++j) {
         __syncthreads();  // previous image fully consumed
         // ---- dz image: [npix_pad][PA], rows >= npix are zero (one "row" of npix_pad pixels for the walker) ----
-        fill_image_s8<NTHR, A_PLANES, 8>(dzi, p.dz_plane, p.dz + (int64_t)j * g.npix * g.cout_p, 1, g.npix, g.cout_p, 0, 0, 1, p.npix_pad,
-                                         p.PA, tid, p.d_dzchunk, p.d_npixpad);
-        fill_input_image<U8, PASSES, NTHR>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, p.PPin, tid, p.d_chunk, p.d_Wp, p.d_R);
+        bool dz_done = false;
+        if constexpr (U8) {
+            if (p.prefetch) {  // (uniform) the dz chunks are requested in front of the frame fill: they travel with its frame-id round trip
+                ImagePrefetch<WgradPrefetch<WV>::DZ_U8> ra;  // instead of costing one of their own (13.9 k cycles to stage an image before)
+                request_image_s8<NTHR>(ra, p.dz + (int64_t)j * g.npix * g.cout_p, 1, g.npix, g.cout_p, 0, 0, 1, p.npix_pad, p.PA, tid,
+                                       p.d_dzchunk, p.d_npixpad);
+                fill_input_image<U8, PASSES, NTHR>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, p.PPin, tid, p.d_chunk, p.d_Wp, p.d_R);
+                commit_image_s8<A_PLANES>(dzi, p.dz_plane, ra);
+                dz_done = true;
+            }
+        }
+        if (!dz_done) {
+            fill_image_s8<NTHR, A_PLANES, 8>(dzi, p.dz_plane, p.dz + (int64_t)j * g.npix * g.cout_p, 1, g.npix, g.cout_p, 0, 0, 1, p.npix_pad,
+                                             p.PA, tid, p.d_dzchunk, p.d_npixpad);
+            fill_input_image<U8, PASSES, NTHR>(img, p.in_plane, g, p.fs, p.in, j, -g.pad, p.R, p.Wp, p.PPin, tid, p.d_chunk, p.d_Wp, p.d_R);
+        }
         __syncthreads();
         if (j == j0) { WG_STAMP(1); } else if (j == j0 + 1) { WG_STAMP(3); }
         k_steps();
@@ -937,6 +951,9 @@ static int launch_conv_wgrad_img(const ConvWgradImgParams& p, int n_img_groups, 
     if (!U8 && p.G >= 2 && p.npix_pad * (p.g.cout_p / 8) <= WgradPrefetch<WV>::DZ * 64 * WV &&
         p.R * p.Wp * (p.g.cin_p / 8) <= WgradPrefetch<WV>::IN * 64 * WV)
         q.prefetch = 1;
+#if !defined(ISDQN_WGRAD_NO_U8_DZ)
+    if (U8 && p.npix_pad * (p.g.cout_p / 8) <= WgradPrefetch<WV>::DZ_U8 * 64 * WV) q.prefetch = 1;
+#endif
 #endif
     hipLaunchKernelGGL((conv_wgrad_img_kernel<MT, NTW, PASSES, U8, WV>), dim3(n_img_groups * p.n_col_groups),
                        dim3(64 * WV), lds, st, q);
