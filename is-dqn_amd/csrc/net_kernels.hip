@@ -1017,6 +1017,17 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, float* _
     }
     if (on) {
         int s = sl;
+        // (eight slabs in flight per thread first: the first layer's weight gradient leaves one slab per image at B = 256 -- 16 dependent
+        // loads per thread in batches of four were four round trips at the tail of the side queue)
+#if !defined(ISDQN_ADAM_4_IN_FLIGHT)
+        for (; s + 7 * 16 < en.n_slabs; s += 8 * 16) {
+            float4 h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = *reinterpret_cast<const float4*>(en.g + (int64_t)(s + u * 16) * en.slab_stride + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { g.x += h[u].x; g.y += h[u].y; g.z += h[u].z; g.w += h[u].w; }
+        }
+#endif
         for (; s + 3 * 16 < en.n_slabs; s += 4 * 16) {
             float4 h[4];
 #pragma unroll
