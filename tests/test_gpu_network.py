@@ -43,6 +43,9 @@ LARGE_BATCH = [
     pytest.param(((8, 8, 8, 16), 9, 9, 515, True), id="tiny-B515-ragged-S2"),
     pytest.param(((8, 8, 8, 16), 2, 3, 1030, False), id="tiny-noln-B1030-ragged-S4"),
     pytest.param(((32, 64, 64, 512), 3, 4, 512, True), id="headline-arch-B512-S2"),
+    # two images per weight-gradient workgroup with a one-image last group: the register prefetch of the next image (conv_img.h:
+    # request_image_s8 / commit_image_s8) has nothing to request there; the backward forks in round 4's order (B <= 768)
+    pytest.param(((32, 64, 64, 512), 3, 4, 131, True), id="headline-arch-B131-ragged-wgrad-groups"),
     # BASELINE configs[4] at its full size (the torch oracle needs ~10 s for it on the GPU box's host cores)
     pytest.param(((32, 64, 64, 512), 32, 4, 1024, True), id="c5-full-size-B1024-K32-A4"),
 ]
